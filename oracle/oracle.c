@@ -1,0 +1,276 @@
+/*
+ * oracle.c -- CPU restatement of the PCCSNet modality-clustering / best-of-K hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and
+ * only as the checker / the reported CPU baseline.  The product path lives in
+ * modular-trajectory-prediction-toolkit_amd/csrc and never links or calls this file.
+ *
+ * What is restated (reference = /root/reference, sklearn = scikit-learn 1.7.2 which the
+ * reference calls at PCCSNet/utils/utility.py:121 -- the k-means arithmetic lives there):
+ *   orc_assign_f32        sklearn cluster/_k_means_lloyd.pyx:168-213 (_update_chunk_dense E-step)
+ *   orc_accumulate_f32    sklearn cluster/_k_means_lloyd.pyx:215-218 + :143-152 (M-step sums)
+ *   orc_average_centers   sklearn cluster/_k_means_common.pyx:274-295
+ *   orc_center_shift      sklearn cluster/_k_means_common.pyx:298-311 (+ :16-43 distance helper)
+ *   orc_inertia_f32       sklearn cluster/_k_means_common.pyx:94-124
+ *   orc_cluster_means_f32 PCCSNet/utils/utility.py:98-105 (get_modality)
+ *   orc_ade_fde_*         PCCSNet/utils/metrics.py:4-23
+ *   orc_best_of_k_*       PCCSNet/train_steps.py:219-233 and
+ *                         StimulusVerification/verify_predictions.py:238-248
+ *
+ * Parity pin: oracle/kmeans_oracle.py drives these functions and is checked against
+ * the tests/golden npz fixtures, which tests/golden/gen_golden.py produced by importing the
+ * reference itself (and scikit-learn) in the build container.
+ *
+ * Arithmetic notes.  The E-step cross term is a k-ordered fmaf chain from 0 followed by
+ * d = fmaf(-2, dot, ||c||^2): this is what an FMA sgemm micro-kernel (OpenBLAS Haswell /
+ * SkylakeX) computes per output element, and it is also exactly what the gfx950
+ * v_mfma_f32_32x32x2_f32 instruction computes.  ||x||^2 is never added (sklearn does not).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_CHUNK 256 /* sklearn cluster/_k_means_common.pyx:13 CHUNK_SIZE */
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------
+ * E-step.  labels[i] = argmin_j ( c2[j] - 2 * <x_i, c_j> ), strict '<', first index wins
+ * (sklearn _k_means_lloyd.pyx:205-213).  Ct is C transposed ([d][k]) so the j loop is
+ * unit-stride; every (i, j) dot product is still a sequential-k fmaf chain.
+ * ---------------------------------------------------------------------------------- */
+#define JB 64
+#define IB 4
+static void assign_chunk(const float *X, int64_t rows, int d, const float *Ct, int k, const float *c2,
+                         int32_t *labels, float *best_out) {
+    for (int64_t i0 = 0; i0 < rows; i0 += IB) {
+        int ib = (int)((rows - i0) < IB ? (rows - i0) : IB);
+        float best[IB];
+        int32_t bidx[IB];
+        for (int a = 0; a < IB; ++a) { best[a] = INFINITY; bidx[a] = 0; }
+        for (int j0 = 0; j0 < k; j0 += JB) {
+            int jb = (k - j0) < JB ? (k - j0) : JB;
+            float acc[IB][JB];
+            for (int a = 0; a < IB; ++a)
+                for (int j = 0; j < JB; ++j) acc[a][j] = 0.0f;
+            for (int kk = 0; kk < d; ++kk) {
+                const float *ct = Ct + (size_t)kk * k + j0;
+                for (int a = 0; a < ib; ++a) {
+                    const float xv = X[(i0 + a) * d + kk];
+#pragma omp simd
+                    for (int j = 0; j < jb; ++j) acc[a][j] = fmaf(xv, ct[j], acc[a][j]);
+                }
+            }
+            for (int a = 0; a < ib; ++a) {
+                for (int j = 0; j < jb; ++j) {
+                    const float dist = fmaf(-2.0f, acc[a][j], c2[j0 + j]);
+                    /* first element initialises, later ones need strict '<' */
+                    if ((j0 + j == 0) || dist < best[a]) { best[a] = dist; bidx[a] = j0 + j; }
+                }
+            }
+        }
+        for (int a = 0; a < ib; ++a) {
+            labels[i0 + a] = bidx[a];
+            if (best_out) best_out[i0 + a] = best[a];
+        }
+    }
+}
+
+void orc_assign_f32(const float *X, int64_t n, int d, const float *C, int k, const float *c2,
+                    int32_t *labels, float *best_out) {
+    float *Ct = (float *)malloc((size_t)d * k * sizeof(float));
+    for (int j = 0; j < k; ++j)
+        for (int kk = 0; kk < d; ++kk) Ct[(size_t)kk * k + j] = C[(size_t)j * d + kk];
+    int64_t n_chunks = (n + ORC_CHUNK - 1) / ORC_CHUNK;
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        int64_t s = c * ORC_CHUNK, e = s + ORC_CHUNK;
+        if (e > n) e = n;
+        assign_chunk(X + s * d, e - s, d, Ct, k, c2, labels + s, best_out ? best_out + s : NULL);
+    }
+    free(Ct);
+}
+
+/* ||row||^2 in the float summation order of NumPy's einsum("ij,ij->i") -- which is what
+ * sklearn.utils.extmath.row_norms(C, squared=True) runs for ||c||^2
+ * (_k_means_lloyd.pyx:99).  Measured on numpy 2.2.6 / x86-64 baseline (SSE, no FMA): four
+ * lane accumulators (element e -> lane e % 4), product rounded then added; full blocks of
+ * 16 elements are consumed vector 3,2,1,0, the remaining vectors in order (zero padded);
+ * horizontal sum (l0 + l1) + (l2 + l3).  tests/test_oracle_golden.py pins this against
+ * np.einsum itself. */
+void orc_row_sqnorm_f32(const float *A, int64_t n, int d, float *out) {
+    for (int64_t i = 0; i < n; ++i) {
+        const float *a = A + i * d;
+        float l[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int e = 0;
+        for (; e + 16 <= d; e += 16)
+            for (int v = 3; v >= 0; --v)
+                for (int q = 0; q < 4; ++q) l[q] = l[q] + a[e + 4 * v + q] * a[e + 4 * v + q];
+        for (; e < d; e += 4)
+            for (int q = 0; q < 4 && e + q < d; ++q) l[q] = l[q] + a[e + q] * a[e + q];
+        out[i] = (l[0] + l[1]) + (l[2] + l[3]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * M-step sums, single-thread sample order in float (what sklearn does with one thread;
+ * with several threads sklearn's own result depends on the lock order, :143-152).
+ * ---------------------------------------------------------------------------------- */
+void orc_accumulate_f32(const float *X, int64_t n, int d, const int32_t *labels, int k, float *sums,
+                        float *weights) {
+    memset(sums, 0, (size_t)k * d * sizeof(float));
+    memset(weights, 0, (size_t)k * sizeof(float));
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t l = labels[i];
+        weights[l] += 1.0f;
+        for (int kk = 0; kk < d; ++kk) sums[(size_t)l * d + kk] += X[i * d + kk];
+    }
+}
+
+/* Same sums in double: the order-independent statement the device path is held to. */
+void orc_accumulate_f64(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,
+                        double *weights) {
+    memset(sums, 0, (size_t)k * d * sizeof(double));
+    memset(weights, 0, (size_t)k * sizeof(double));
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t l = labels[i];
+        weights[l] += 1.0;
+        for (int kk = 0; kk < d; ++kk) sums[(size_t)l * d + kk] += (double)X[i * d + kk];
+    }
+}
+
+/* sklearn _k_means_common.pyx:274-295: alpha = 1/w ; c *= alpha ; empty -> copy of the
+ * heaviest cluster's (already averaged or not, in index order) centre. */
+void orc_average_centers(float *centers, const float *weights, int k, int d) {
+    int argmax = 0;
+    for (int j = 1; j < k; ++j)
+        if (weights[j] > weights[argmax]) argmax = j;
+    for (int j = 0; j < k; ++j) {
+        if (weights[j] > 0) {
+            const float alpha = 1.0f / weights[j];
+            for (int kk = 0; kk < d; ++kk) centers[(size_t)j * d + kk] *= alpha;
+        } else {
+            for (int kk = 0; kk < d; ++kk) centers[(size_t)j * d + kk] = centers[(size_t)argmax * d + kk];
+        }
+    }
+}
+
+/* sklearn _k_means_common.pyx:16-43, float instantiation: groups of four, then remainder. */
+static float euclid_sq_f32(const float *a, const float *b, int d) {
+    const int n4 = d / 4, rem = d % 4;
+    float result = 0.0f;
+    for (int i = 0; i < n4; ++i) {
+        result += ((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) +
+                   (a[2] - b[2]) * (a[2] - b[2]) + (a[3] - b[3]) * (a[3] - b[3]));
+        a += 4;
+        b += 4;
+    }
+    for (int i = 0; i < rem; ++i) result += (a[i] - b[i]) * (a[i] - b[i]);
+    return result;
+}
+
+/* sklearn _k_means_common.pyx:298-311: per-centre Euclidean shift (not squared). */
+void orc_center_shift(const float *c_old, const float *c_new, int k, int d, float *shift) {
+    for (int j = 0; j < k; ++j) shift[j] = sqrtf(euclid_sq_f32(c_new + (size_t)j * d, c_old + (size_t)j * d, d));
+}
+
+/* sklearn _k_means_common.pyx:94-124; per-point term in float as there, the sum over
+ * points in double (sklearn's float sum order depends on its thread count). */
+double orc_inertia_f32(const float *X, int64_t n, int d, const float *C, const int32_t *labels,
+                       float *per_point) {
+    double tot = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float v = euclid_sq_f32(X + i * d, C + (size_t)labels[i] * d, d);
+        if (per_point) per_point[i] = v;
+        tot += (double)v;
+    }
+    return tot;
+}
+
+/* PCCSNet/utils/utility.py:98-105 get_modality: per-cluster mean of the member rows.
+ * Sum in double, one rounding.  counts[j]==0 leaves the row untouched; the Python side
+ * raises KeyError like the reference's dict lookup does. */
+void orc_cluster_means_f32(const float *X, int64_t n, int d, const int32_t *labels, int k, float *means,
+                           int64_t *counts) {
+    double *s = (double *)calloc((size_t)k * d, sizeof(double));
+    memset(counts, 0, (size_t)k * sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t l = labels[i];
+        counts[l] += 1;
+        for (int kk = 0; kk < d; ++kk) s[(size_t)l * d + kk] += (double)X[i * d + kk];
+    }
+    for (int j = 0; j < k; ++j)
+        if (counts[j] > 0)
+            for (int kk = 0; kk < d; ++kk) means[(size_t)j * d + kk] = (float)(s[(size_t)j * d + kk] / (double)counts[j]);
+    free(s);
+}
+
+/* ------------------------------------------------------------------------------------
+ * ADE / FDE.  pred [n, kstride, t, 2] (only the first k candidates of each agent are
+ * scored), gt [n, t, 2].  ade[n*k+c] = sum_t ||gt - pred|| / ade_div, fde = last step.
+ * PCCSNet/utils/metrics.py:4-23 with the caller's "/ args.pred_len" (train_steps.py:219).
+ * ---------------------------------------------------------------------------------- */
+#define ORC_ADE_FDE(NAME, T)                                                                          \
+    void NAME(const T *pred, const T *gt, int64_t n, int k, int kstride, int t, T ade_div, T *ade,   \
+              T *fde) {                                                                               \
+        for (int64_t a = 0; a < n; ++a)                                                               \
+            for (int c = 0; c < k; ++c) {                                                             \
+                const T *p = pred + ((size_t)a * kstride + c) * t * 2;                                \
+                const T *g = gt + (size_t)a * t * 2;                                                  \
+                T s = 0, last = 0;                                                                    \
+                for (int q = 0; q < t; ++q) {                                                         \
+                    const T dx = g[2 * q] - p[2 * q], dy = g[2 * q + 1] - p[2 * q + 1];               \
+                    last = (T)sqrt((double)(dx * dx + dy * dy));                                      \
+                    s += last;                                                                        \
+                }                                                                                     \
+                ade[(size_t)a * k + c] = s / ade_div;                                                 \
+                fde[(size_t)a * k + c] = last;                                                        \
+            }                                                                                         \
+    }
+ORC_ADE_FDE(orc_ade_fde_f32, float)
+ORC_ADE_FDE(orc_ade_fde_f64, double)
+
+/* Best-of-K selection, PCCSNet/train_steps.py:222-230:
+ *   mode 0 ADE-prioritised: i = argmin ADE, report (ADE[i], FDE[i])
+ *   mode 1 FDE-prioritised: i = argmin FDE, report (ADE[i], FDE[i])
+ *   mode 2 equal focus    : (min ADE, min FDE) independently; idx = argmin ADE, idx2 = argmin FDE
+ * argmin = first occurrence of the minimum (torch.argmin / np.argmin).
+ * sums[0], sums[1] = double sums over agents of the reported pair (train_steps.py:232). */
+#define ORC_BEST_OF_K(NAME, ADEFDE, T)                                                                \
+    void NAME(const T *pred, const T *gt, int64_t n, int k, int kstride, int t, T ade_div, int mode, \
+              T *min_ade, T *min_fde, int32_t *idx, int32_t *idx2, double *sums) {                    \
+        T *ade = (T *)malloc((size_t)k * sizeof(T)), *fde = (T *)malloc((size_t)k * sizeof(T));       \
+        double sa = 0.0, sf = 0.0;                                                                    \
+        for (int64_t a = 0; a < n; ++a) {                                                             \
+            ADEFDE(pred + (size_t)a * kstride * t * 2, gt + (size_t)a * t * 2, 1, k, kstride, t,      \
+                   ade_div, ade, fde);                                                                \
+            int ia = 0, jf = 0;                                                                       \
+            for (int c = 1; c < k; ++c) {                                                             \
+                if (ade[c] < ade[ia]) ia = c;                                                         \
+                if (fde[c] < fde[jf]) jf = c;                                                         \
+            }                                                                                         \
+            T ra, rf;                                                                                 \
+            int i1, i2;                                                                               \
+            if (mode == 0) { ra = ade[ia]; rf = fde[ia]; i1 = ia; i2 = ia; }                          \
+            else if (mode == 1) { ra = ade[jf]; rf = fde[jf]; i1 = jf; i2 = jf; }                     \
+            else { ra = ade[ia]; rf = fde[jf]; i1 = ia; i2 = jf; }                                    \
+            min_ade[a] = ra; min_fde[a] = rf; idx[a] = i1;                                            \
+            if (idx2) idx2[a] = i2;                                                                   \
+            sa += (double)ra; sf += (double)rf;                                                       \
+        }                                                                                             \
+        sums[0] = sa; sums[1] = sf;                                                                   \
+        free(ade); free(fde);                                                                         \
+    }
+ORC_BEST_OF_K(orc_best_of_k_f32, orc_ade_fde_f32, float)
+ORC_BEST_OF_K(orc_best_of_k_f64, orc_ade_fde_f64, double)

@@ -1,0 +1,212 @@
+"""Generate tests/golden/*.npz from the reference itself.
+
+Run ONLY in the build container (needs /root/reference and scikit-learn 1.7.2):
+
+    python tests/golden/gen_golden.py
+
+It imports the reference's modules from /root/reference (never copies them) and
+scikit-learn -- the third-party package that holds the reference's k-means arithmetic
+(PCCSNet/utils/utility.py:121) -- runs them on the integer-built inputs of datagen.py and
+stores the expected outputs.  The fixtures contain data only.
+"""
+import argparse
+import importlib
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import datagen  # noqa: E402
+
+REF = "/root/reference"
+
+
+def _import_ref(subdir):
+    """Import <REF>/<subdir>/utils/{utility,metrics}.py under a clean ``utils`` namespace."""
+    for m in [m for m in sys.modules if m == "utils" or m.startswith("utils.")]:
+        del sys.modules[m]
+    path = os.path.join(REF, subdir)
+    sys.path.insert(0, path)
+    try:
+        utility = importlib.import_module("utils.utility")
+        metrics = importlib.import_module("utils.metrics")
+    finally:
+        sys.path.remove(path)
+    return utility, metrics
+
+
+def save(name, **kw):
+    p = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(p, **kw)
+    print("wrote", p, os.path.getsize(p), "bytes")
+
+
+G1_CASES = [
+    # name, seed, n, d, k_true, K, spread, noise
+    ("g1_n2048_d96_k32", 11, 2048, 96, 32, 32, 2600, 160),
+    ("g1_n6000_d96_k200", 12, 6000, 96, 150, 200, 2600, 160),
+    ("g1_n4096_d128_k64", 13, 4096, 128, 48, 64, 2600, 160),
+    # overlapping modes, K >> k_true: ~20 Lloyd iterations with many close calls
+    ("g1_hard_n5000_d96_k64", 14, 5000, 96, 8, 64, 1500, 900),
+]
+
+
+def gen_g1(utility):
+    from sklearn.cluster import KMeans
+    from sklearn.cluster._k_means_lloyd import lloyd_iter_chunked_dense
+    from sklearn.cluster._kmeans import _tolerance
+
+    for name, seed, n, d, k_true, K, spread, noise in G1_CASES:
+        X = datagen.make_encodings(seed, n, d, k_true, spread, noise)
+        idx0 = datagen.make_init_indices(seed + 1000, n, K)
+        C0 = X[idx0].copy()
+        km = KMeans(n_clusters=K, init=C0, n_init=1).fit(X)
+        # one raw Lloyd iteration on the centred data, one thread (deterministic float sums)
+        x_mean = X.mean(axis=0)
+        Xc = X - x_mean
+        C0c = C0 - x_mean
+        c_new = np.zeros_like(C0c)
+        w = np.zeros(K, dtype=np.float32)
+        lab1 = np.full(n, -1, dtype=np.int32)
+        shift = np.zeros(K, dtype=np.float32)
+        lloyd_iter_chunked_dense(Xc, np.ones(n, dtype=np.float32), C0c, c_new, w, lab1, shift, 1)
+        # G3: the reference's get_modality on the final labels
+        mod = utility.get_modality(torch.from_numpy(X), km.labels_, K).numpy()
+        save(name, seed=seed, n=n, d=d, k_true=k_true, K=K, spread=spread, noise=noise, idx0=idx0,
+             labels=km.labels_.astype(np.int32), centers=km.cluster_centers_, inertia=np.float64(km.inertia_),
+             n_iter=km.n_iter_, tol_abs=np.float64(_tolerance(X, 1e-4)), x_mean=x_mean,
+             iter1_labels=lab1, iter1_centers=c_new, iter1_weights=w, iter1_shift=shift,
+             modality=mod)
+
+
+def gen_g2(utility):
+    X = datagen.make_encodings(21, 3000, 96, 20)
+    np.random.seed(0)
+    labels, sizes = utility.cluster_data(X.copy(), 20)
+    save("g2_seeded_cluster_data", seed=21, n=3000, d=96, k_true=20, K=20, np_seed=0,
+         labels=labels, sizes=sizes)
+    # k-means++ alone, on centred data as KMeans.fit calls it
+    from sklearn.cluster._kmeans import _kmeans_plusplus
+    from sklearn.utils.extmath import row_norms
+    Xc = X - X.mean(axis=0)
+    _, ind = _kmeans_plusplus(Xc, 20, row_norms(Xc, squared=True), np.ones(3000, dtype=np.float32),
+                              np.random.RandomState(5))
+    save("g9_kmeanspp", seed=21, n=3000, d=96, k_true=20, K=20, rs_seed=5, indices=ind)
+
+
+def gen_g4_g5():
+    from sklearn.cluster import KMeans
+    # sklearn/cluster/tests/test_k_means.py:85-111 (relocated clusters), float64 like the KAT
+    X = np.array([[0, 0], [0.5, 0], [0.5, 1], [1, 1]], dtype=np.float64)
+    init = np.array([[0.5, 0.5], [3, 3]], dtype=np.float64)
+    km = KMeans(n_clusters=2, n_init=1, init=init).fit(X)
+    X32 = X.astype(np.float32)
+    km32 = KMeans(n_clusters=2, n_init=1, init=init.astype(np.float32)).fit(X32)
+    save("g4_relocated_clusters", X=X, init=init, labels=km.labels_, centers=km.cluster_centers_,
+         inertia=km.inertia_, n_iter=km.n_iter_, labels32=km32.labels_, centers32=km32.cluster_centers_,
+         inertia32=km32.inertia_, n_iter32=km32.n_iter_)
+    # sklearn/cluster/tests/test_k_means.py:62-80 (hand-computed results); the KAT's sample
+    # weights [3,1,1,3] are restated as repeated rows (the reference never passes weights)
+    Xw = np.array([[0, 0]] * 3 + [[0.5, 0], [0.5, 1]] + [[1, 1]] * 3, dtype=np.float32)
+    init5 = np.array([[0, 0], [1, 1]], dtype=np.float32)
+    km5 = KMeans(n_clusters=2, n_init=1, init=init5).fit(Xw)
+    assert list(km5.labels_) == [0, 0, 0, 0, 1, 1, 1, 1] and km5.n_iter_ == 2
+    assert np.allclose(km5.cluster_centers_, [[0.125, 0], [0.875, 1]]) and np.isclose(km5.inertia_, 0.375)
+    save("g5_kat_results", X=Xw, init=init5, labels=km5.labels_, centers=km5.cluster_centers_,
+         inertia=km5.inertia_, n_iter=km5.n_iter_)
+
+
+def gen_g6(metrics):
+    n, k, t = 64, 20, 12
+    pred, gt = datagen.make_trajectories(31, n, k, t)
+    # exact tie: agent 5's candidates 3 and 7 are identical and the best -> first index must win
+    pred[5, 3] = gt[5] + np.float32(1.0 / 4096)
+    pred[5, 7] = pred[5, 3]
+    # exact FDE tie with different ADE: agent 9, candidates 2 and 11 share the last step
+    pred[9, 2, -1] = gt[9, -1]
+    pred[9, 11, -1] = gt[9, -1]
+    tp, tg = torch.from_numpy(pred), torch.from_numpy(gt)
+    ade = np.empty((n, k), dtype=np.float32)
+    fde = np.empty((n, k), dtype=np.float32)
+    res = {}
+    for mode in (0, 1, 2):
+        val = np.zeros(2).astype(float)
+        mins = np.empty((n, 2), dtype=np.float32)
+        idx = np.empty(n, dtype=np.int64)
+        for i in range(n):  # PCCSNet/train_steps.py:214-232 with batch_size 1
+            out, g = tp[i], tg[i:i + 1]
+            A = metrics.displacement_error(out, g) / t
+            F = metrics.final_displacement_error(out[:, -1], g[:, -1])
+            ade[i], fde[i] = A.numpy(), F.numpy()
+            if mode == 0:
+                j = torch.argmin(A)
+                a, f = A[j].item(), F[j].item()
+            elif mode == 1:
+                j = torch.argmin(F)
+                a, f = A[j].item(), F[j].item()
+            else:
+                j = torch.argmin(A)
+                a, f = torch.min(A).item(), torch.min(F).item()
+            val += [a, f]
+            mins[i] = (a, f)
+            idx[i] = int(j)
+        val /= n
+        res[f"mode{mode}_mins"] = mins
+        res[f"mode{mode}_idx"] = idx
+        res[f"mode{mode}_val"] = val
+    ade_sum = metrics.displacement_error(tp[0], tg[0:1], mode="sum").item()
+    fde_sum = metrics.final_displacement_error(tp[0][:, -1], tg[0:1][:, -1], mode="sum").item()
+    save("g6_ade_fde", seed=31, n=n, k=k, t=t, ade=ade, fde=fde, ade_sum0=ade_sum, fde_sum0=fde_sum, **res)
+
+
+def gen_g7():
+    # StimulusVerification/verify_predictions.py:238-248 is a top-level script (argparse +
+    # file loads) and cannot be imported; its "Before Verification" block is evaluated here
+    # with the same NumPy calls on [N,200,12,2] float64 predictions, best_of=20.
+    n, ktot, t, best_of = 32, 200, 12, 20
+    pred, fut = datagen.make_trajectories(41, n, ktot, t, dtype=np.float64)
+    out = {}
+    for fde_prio in (False, True):
+        diff = np.linalg.norm(pred[:, :best_of] - fut[:, None], axis=-1)
+        tot_a = tot_f = 0
+        idx = np.empty(n, dtype=np.int64)
+        for i in range(n):
+            j = np.argmin(diff[i, :, -1]) if fde_prio else np.argmin(np.sum(diff[i], axis=-1))
+            tot_f += diff[i, j, -1]
+            tot_a += np.sum(diff[i, j])
+            idx[i] = j
+        tag = "fdeprio" if fde_prio else "adeprio"
+        out[tag + "_ade"] = tot_a / n / t
+        out[tag + "_fde"] = tot_f / n
+        out[tag + "_idx"] = idx
+    save("g7_verify_best_of_20", seed=41, n=n, ktot=ktot, t=t, best_of=best_of, **out)
+
+
+def gen_g8():
+    # the XOE copy imports itself as ``PCCSNet_XOE.utils...`` from MomentaryPrediction/
+    sys.path.insert(0, os.path.join(REF, "MomentaryPrediction"))
+    try:
+        xoe_utility = importlib.import_module("PCCSNet_XOE.utils.utility")
+    finally:
+        sys.path.pop(0)
+    X = datagen.make_encodings(51, 2500, 96, 16)
+    args = argparse.Namespace(pm=0.02, obs_feat_size=48)
+    np.random.seed(3)
+    labels, sizes = xoe_utility.cluster_data(X.copy(), n_cluster=16, save_dir=None, args=args)
+    save("g8_xoe_pm", seed=51, n=2500, d=96, k_true=16, K=16, np_seed=3, pm=0.02, obs_feat_size=48,
+         labels=labels, sizes=sizes)
+
+
+if __name__ == "__main__":
+    warnings.simplefilter("error")  # a ConvergenceWarning here means a bad fixture
+    utility, metrics = _import_ref("PCCSNet")
+    only = sys.argv[1:]
+    jobs = dict(g1=lambda: gen_g1(utility), g2=lambda: gen_g2(utility), g45=gen_g4_g5,
+                g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8)
+    for name, fn in jobs.items():
+        if not only or name in only:
+            fn()
