@@ -1,0 +1,174 @@
+/*
+ * mtp_accel.h -- C-ABI of the MI355X (gfx950) implementation of PCCSNet's
+ * modality-clustering / best-of-K hot path.
+ *
+ * The reference (ApeironY/Modular-Trajectory-Prediction-Toolkit) is pure Python and has no
+ * FFI of its own: its boundary for this path is a set of module-level Python functions
+ * (PCCSNet/utils/utility.py, PCCSNet/utils/metrics.py, PCCSNet/train_steps.py:202-239).
+ * The entry points below are what a ctypes binding placed behind those functions binds;
+ * each comment cites the reference code the entry point replaces.  INTEGRATION.md shows the
+ * binding; modular-trajectory-prediction-toolkit_amd/pccs_accel is the host-side mirror.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes.  Every array pointer is a DEVICE pointer owned by
+ *    the caller (e.g. torch tensor .data_ptr()), row-major, 16-byte aligned.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only
+ *    enqueue work unless stated otherwise; they never allocate or free device memory.
+ *  - Return value: 0 = OK, negative = error (MTP_E_*); mtp_last_error() then returns a
+ *    thread-local message.  No exceptions cross the boundary.
+ *  - float arrays are IEEE binary32, labels are int32, counters/sums are binary64.
+ */
+#ifndef MTP_ACCEL_H
+#define MTP_ACCEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTP_OK 0
+#define MTP_E_ARG (-1)      /* bad argument (shape, alignment, null pointer) */
+#define MTP_E_HIP (-2)      /* a HIP runtime call failed */
+#define MTP_E_WORKSPACE (-3) /* workspace too small */
+
+/* Lloyd loop states (flags[MTP_FLAG_STATE]) */
+#define MTP_STATE_RUNNING 0
+#define MTP_STATE_STRICT 1   /* labels == labels_old: sklearn "strict convergence" */
+#define MTP_STATE_TOL 2      /* sum_j shift_j^2 <= tol: needs one more E-step */
+#define MTP_STATE_RELOCATE 3 /* an empty cluster needs relocation before the M-step */
+#define MTP_STATE_MAXITER 4  /* max_iter reached: needs one more E-step */
+
+/* int32 flag words shared by the Lloyd step entry points */
+#define MTP_FLAG_STATE 0
+#define MTP_FLAG_N_ITER 1
+#define MTP_FLAG_N_EMPTY 2
+#define MTP_FLAG_WORDS 8
+
+const char *mtp_last_error(void);
+int mtp_version(void);
+
+/* Number of floats of the staged centroid image the E-step kernel streams through LDS
+ * (MFMA operand order, 32-centroid tiles, ||c||^2 appended per tile).  0 if (k, d) uses the
+ * generic E-step kernel, which reads the plain [k, d] matrix. */
+int64_t mtp_staged_centers_floats(int k, int d);
+
+/* Bytes of scratch mtp_assign_f32 / mtp_lloyd_f32 need for (k, d). */
+int64_t mtp_assign_workspace_bytes(int k, int d);
+int64_t mtp_lloyd_workspace_bytes(int k, int d);
+
+/* ||A_i||^2 per row, in NumPy einsum("ij,ij->i") float order.
+ * Replaces sklearn.utils.extmath.row_norms(centers, squared=True), sklearn
+ * cluster/_k_means_lloyd.pyx:99. */
+int mtp_row_sqnorm_f32(const float *A, int64_t n, int d, float *out, void *stream);
+
+/* Column sums (double, += into col_sum[d]) and sums of squared deviations from `mean`
+ * (double, += into col_sqdev[d]); X -= mean in place.
+ * Replace X.mean(axis=0) / np.var(X, axis=0) / X -= X_mean of sklearn
+ * cluster/_kmeans.py:279-287 and :1478-1481 (KMeans.fit preprocessing). */
+int mtp_col_sums_f32(const float *X, int64_t n, int d, double *col_sum, void *stream);
+int mtp_col_sqdev_f32(const float *X, int64_t n, int d, const double *mean, double *col_sqdev, void *stream);
+int mtp_sub_rowvec_f32(float *X, int64_t n, int d, const float *vec, void *stream);
+
+/* E-step: labels[i] = argmin_j (||c_j||^2 - 2 x_i.c_j), strict '<', lowest index wins.
+ * Replaces sklearn cluster/_k_means_lloyd.pyx:168-213 (_update_chunk_dense, E part) -- the
+ * "nearest-modality assignment" of PCCSNet/train_steps.py:357.
+ *   c2        [k] ||c_j||^2, or NULL to compute it (einsum order) from C
+ *   labels    [n] in/out: previous labels in, new labels out
+ *   n_changed NULL, or one double that is incremented by #(labels[i] changed)
+ *   ws        mtp_assign_workspace_bytes(k, d) bytes of device scratch */
+int mtp_assign_f32(const float *X, int64_t n, int d, const float *C, int k, const float *c2, int32_t *labels,
+                   double *n_changed, void *ws, size_t ws_bytes, void *stream);
+
+/* M-step sums: sums[k, d] += sum of member rows, counts[k] += member count (doubles).
+ * Replaces sklearn cluster/_k_means_lloyd.pyx:215-218 + :143-152 and the per-cluster
+ * gather of PCCSNet/utils/utility.py:98-104 (get_modality). */
+int mtp_centroid_sums_f32(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,
+                          double *counts, void *stream);
+
+/* means[j, :] = sums[j, :] / counts[j] rounded once to float (rows with count 0 are left
+ * untouched; *n_empty_out, a device int32, receives their number).
+ * Replaces torch.mean(memory_data[cluster_dict[i]], dim=0), PCCSNet/utils/utility.py:103-105. */
+int mtp_cluster_means_f32(const double *sums, const double *counts, int k, int d, float *means,
+                          int32_t *n_empty_out, void *stream);
+
+/* Inertia: *inertia += sum_i ||x_i - c_{labels[i]}||^2 (per-point term in float with
+ * sklearn's grouping, sum in double).  Replaces sklearn cluster/_k_means_common.pyx:94-124.
+ * per_point may be NULL; otherwise receives the n per-point squared distances. */
+int mtp_inertia_f32(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
+                    float *per_point, void *stream);
+
+/* ---- Lloyd iteration, step level (multi-GPU drivers interleave an all-reduce of `red`) ----
+ * red      double [k*d + k + 2]: sums, counts, n_changed, spare  (the all-reduced buffer)
+ * flags    int32  [MTP_FLAG_WORDS]
+ * staged   float  [mtp_staged_centers_floats(k, d)] (may be NULL when that is 0)
+ * c2       float  [k]
+ * All three entry points are no-ops while flags[MTP_FLAG_STATE] != MTP_STATE_RUNNING. */
+
+/* Stage the initial centres: staged/c2 from C, zero red, flags = {RUNNING, 0, 0}. */
+int mtp_lloyd_begin_f32(const float *C, int k, int d, float *staged, float *c2, double *red, int32_t *flags,
+                        void *stream);
+
+/* E-step + local M-step sums of one iteration (sklearn _k_means_lloyd.pyx:118-152):
+ * labels in/out, red += local sums / counts / n_changed. */
+int mtp_lloyd_estep_f32(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2,
+                        int k, int32_t *labels, double *red, const int32_t *flags, void *stream);
+
+/* Finish the iteration from the (all-reduced) red buffer: average (alpha = 1/w, c *= alpha),
+ * centre shift, strict / tol convergence (sklearn _k_means_common.pyx:274-311 and
+ * _kmeans.py:715-734).  C_new, staged, c2, shift[k] are written, red is zeroed, flags updated.
+ * If a cluster is empty and relocation_done == 0 nothing is written except
+ * flags = {RELOCATE, n_iter, n_empty}; the caller then runs mtp_far_points_f32 +
+ * mtp_apply_relocation_f32 and calls this again with relocation_done = 1. */
+int mtp_lloyd_mstep_f32(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
+                        int relocation_done, float *staged, float *c2, float *shift, int32_t *flags,
+                        void *stream);
+
+/* Empty-cluster relocation, sklearn cluster/_k_means_common.pyx:167-211.
+ * mtp_far_points_f32: the m points farthest from their assigned (old) centre, by
+ * descending ||x - c||^2 (float, direct form), ties to the lowest index:
+ *   far_val[m] float, far_idx[m] int64 (row index + idx_offset), far_lab[m] int32,
+ *   far_rows[m, d] float.  dist_scratch: n floats. */
+int mtp_far_points_f32(const float *X, int64_t n, int d, const float *C_old, const int32_t *labels, int m,
+                       int64_t idx_offset, float *far_val, int64_t *far_idx, int32_t *far_lab,
+                       float *far_rows, float *dist_scratch, void *stream);
+/* Apply: the i-th empty cluster (ascending id) takes far_rows[i]; its old cluster loses it.
+ * Skipped entirely when far_val[0] == 0 (more clusters than distinct points). */
+int mtp_apply_relocation_f32(double *red, int k, int d, int m, const float *far_val, const int32_t *far_lab,
+                             const float *far_rows, void *stream);
+
+/* Whole single-GPU Lloyd run == sklearn _kmeans_single_lloyd (cluster/_kmeans.py:624-752) on
+ * already-centred data.  Synchronises the stream every `check_every` iterations to read the
+ * flags; kernels of iterations enqueued past convergence are no-ops.
+ *   C_inout [k, d] initial centres in, final centres out;  labels_out [n]
+ *   inertia_out: 1 double (device);  n_iter_out: 1 int (HOST pointer)
+ *   ws: mtp_lloyd_workspace_bytes(k, d) + n*4 bytes of device scratch */
+int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int max_iter, double tol_abs,
+                  int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, void *ws,
+                  size_t ws_bytes, void *stream);
+
+/* Best-of-K ADE/FDE.  pred [n, kstride, t, 2], gt [n, t, 2]; the first k (<= kstride)
+ * candidates of every agent are scored:
+ *   ADE_c = (sum_t ||gt_t - pred_c,t||) / ade_div,  FDE_c = ||gt_T - pred_c,T||
+ *   mode 0: i = argmin ADE -> (ADE_i, FDE_i); mode 1: i = argmin FDE -> (ADE_i, FDE_i);
+ *   mode 2: (min ADE, min FDE) independently (idx = argmin ADE, idx2 = argmin FDE).
+ * argmin = first minimum.  sums[0..1] (doubles) += sum over agents of the reported pair.
+ * Replaces PCCSNet/utils/metrics.py:4-23 + PCCSNet/train_steps.py:219-232, and (f64,
+ * ade_div = 1) StimulusVerification/verify_predictions.py:238-247.
+ * min_ade/min_fde/idx/idx2 may each be NULL. */
+int mtp_best_of_k_f32(const float *pred, const float *gt, int64_t n, int k, int kstride, int t, float ade_div,
+                      int mode, float *min_ade, float *min_fde, int32_t *idx, int32_t *idx2, double *sums,
+                      void *stream);
+int mtp_best_of_k_f64(const double *pred, const double *gt, int64_t n, int k, int kstride, int t,
+                      double ade_div, int mode, double *min_ade, double *min_fde, int32_t *idx, int32_t *idx2,
+                      double *sums, void *stream);
+
+/* Per-candidate ADE / FDE ("raw" mode of metrics.py:4-23): ade[n*k], fde[n*k]. */
+int mtp_ade_fde_f32(const float *pred, const float *gt, int64_t n, int k, int kstride, int t, float ade_div,
+                    float *ade, float *fde, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTP_ACCEL_H */

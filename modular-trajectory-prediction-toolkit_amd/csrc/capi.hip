@@ -1,0 +1,213 @@
+// C-ABI entry points of libmtp_accel.so (see include/mtp_accel.h) and the single-GPU Lloyd driver.
+#include <cstring>
+
+#include "mtp_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void mtp_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *mtp_last_error(void) { return g_err; }
+extern "C" int mtp_version(void) { return 100; }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int64_t mtp_staged_centers_floats(int k, int d) {
+    if (k <= 0 || d <= 0 || !mtp_mfma_dim(d)) return 0;
+    return (int64_t)mtp_n_tiles(k) * mtp_tile_floats(d);
+}
+
+extern "C" int64_t mtp_assign_workspace_bytes(int k, int d) {
+    if (k <= 0 || d <= 0) return 0;
+    return (int64_t)(align_up((size_t)mtp_staged_centers_floats(k, d) * 4, 256) + align_up((size_t)k * 4, 256));
+}
+
+// Lloyd workspace carve (all offsets multiples of 256 bytes)
+struct LloydWs {
+    double *red;
+    float *c_alt, *staged, *c2, *shift;
+    int32_t *flags;
+    float *far_val;
+    int64_t *far_idx;
+    int32_t *far_lab;
+    float *far_rows;
+    size_t bytes;
+};
+static constexpr int MTP_MAX_RELOC = 64;  // empty clusters relocated per iteration, at most
+
+static LloydWs carve_lloyd(void *ws, int k, int d) {
+    LloydWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *p = ws ? static_cast<char *>(ws) + off : nullptr;
+        off += align_up(bytes, 256);
+        return p;
+    };
+    w.red = static_cast<double *>(take((size_t)mtp_red_len(k, d) * 8));
+    w.c_alt = static_cast<float *>(take((size_t)k * d * 4));
+    w.staged = static_cast<float *>(take((size_t)mtp_staged_centers_floats(k, d) * 4 + 16));
+    w.c2 = static_cast<float *>(take((size_t)k * 4));
+    w.shift = static_cast<float *>(take((size_t)k * 4));
+    w.flags = static_cast<int32_t *>(take(MTP_FLAG_WORDS * 4));
+    w.far_val = static_cast<float *>(take(MTP_MAX_RELOC * 4));
+    w.far_idx = static_cast<int64_t *>(take(MTP_MAX_RELOC * 8));
+    w.far_lab = static_cast<int32_t *>(take(MTP_MAX_RELOC * 4));
+    w.far_rows = static_cast<float *>(take((size_t)MTP_MAX_RELOC * d * 4));
+    w.bytes = off;
+    return w;
+}
+
+extern "C" int64_t mtp_lloyd_workspace_bytes(int k, int d) {
+    if (k <= 0 || d <= 0) return 0;
+    return (int64_t)carve_lloyd(nullptr, k, d).bytes;
+}
+
+extern "C" int mtp_assign_f32(const float *X, int64_t n, int d, const float *C, int k, const float *c2, int32_t *labels,
+                              double *n_changed, void *ws, size_t ws_bytes, void *stream) {
+    MTP_REQUIRE(X && C && labels, "mtp_assign: null pointer");
+    MTP_REQUIRE(n >= 0 && d >= 1 && k >= 1, "mtp_assign: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
+    if ((size_t)mtp_assign_workspace_bytes(k, d) > ws_bytes || ws == nullptr) {
+        mtp_set_error("mtp_assign: workspace of %zu bytes, need %lld", ws_bytes, (long long)mtp_assign_workspace_bytes(k, d));
+        return MTP_E_WORKSPACE;
+    }
+    hipStream_t s = mtp_stream(stream);
+    float *staged = static_cast<float *>(ws);
+    float *c2w = reinterpret_cast<float *>(static_cast<char *>(ws) + align_up((size_t)mtp_staged_centers_floats(k, d) * 4, 256));
+    if (c2 != nullptr && mtp_mfma_dim(d)) {
+        mtp_set_error("mtp_assign: caller-provided c2 is only honoured by the generic (non-MFMA) kernel; pass NULL");
+        return MTP_E_ARG;
+    }
+    // stage C (and ||c||^2 unless the caller brought its own)
+    int rc = mtp_launch_stage_centers(C, k, d, staged, c2w, nullptr, s);
+    if (rc != MTP_OK) return rc;
+    return mtp_launch_assign(X, n, d, C, staged, c2 ? c2 : c2w, k, labels, n_changed, nullptr, s);
+}
+
+extern "C" int mtp_centroid_sums_f32(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,
+                                     double *counts, void *stream) {
+    MTP_REQUIRE(X && labels && sums && counts, "mtp_centroid_sums: null pointer");
+    MTP_REQUIRE(n >= 0 && d >= 1 && k >= 1, "mtp_centroid_sums: bad shape");
+    return mtp_launch_accumulate(X, n, d, labels, k, sums, counts, nullptr, mtp_stream(stream));
+}
+
+extern "C" int mtp_inertia_f32(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
+                               float *per_point, void *stream) {
+    MTP_REQUIRE(X && C && labels && (inertia || per_point), "mtp_inertia: null pointer");
+    return mtp_launch_inertia(X, n, d, C, labels, inertia, per_point, mtp_stream(stream));
+}
+
+// ---- step-level Lloyd API ----
+extern "C" int mtp_lloyd_begin_f32(const float *C, int k, int d, float *staged, float *c2, double *red, int32_t *flags,
+                                   void *stream) {
+    MTP_REQUIRE(C && c2 && red && flags && k >= 1 && d >= 1, "mtp_lloyd_begin: bad arguments");
+    MTP_REQUIRE(!mtp_mfma_dim(d) || staged, "mtp_lloyd_begin: staged image buffer missing");
+    hipStream_t s = mtp_stream(stream);
+    MTP_HIP(hipMemsetAsync(red, 0, (size_t)mtp_red_len(k, d) * 8, s));
+    MTP_HIP(hipMemsetAsync(flags, 0, MTP_FLAG_WORDS * 4, s));
+    return mtp_launch_stage_centers(C, k, d, staged, c2, nullptr, s);
+}
+
+extern "C" int mtp_lloyd_estep_f32(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2,
+                                   int k, int32_t *labels, double *red, const int32_t *flags, void *stream) {
+    MTP_REQUIRE(X && C && c2 && labels && red && flags, "mtp_lloyd_estep: null pointer");
+    hipStream_t s = mtp_stream(stream);
+    int rc = mtp_launch_assign(X, n, d, C, staged, c2, k, labels, red + (size_t)k * d + k, flags + MTP_FLAG_STATE, s);
+    if (rc != MTP_OK) return rc;
+    return mtp_launch_accumulate(X, n, d, labels, k, red, red + (size_t)k * d, flags + MTP_FLAG_STATE, s);
+}
+
+extern "C" int mtp_lloyd_mstep_f32(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
+                                   int relocation_done, float *staged, float *c2, float *shift, int32_t *flags,
+                                   void *stream) {
+    MTP_REQUIRE(red && C_old && C_new && c2 && shift && flags && C_old != C_new, "mtp_lloyd_mstep: bad arguments");
+    return mtp_launch_mstep(red, C_old, C_new, k, d, tol, max_iter, relocation_done, staged, c2, shift, flags,
+                            mtp_stream(stream));
+}
+
+// ---- whole single-GPU run: sklearn _kmeans_single_lloyd (cluster/_kmeans.py:624-752) ----
+extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int max_iter, double tol_abs,
+                             int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, void *ws,
+                             size_t ws_bytes, void *stream) {
+    MTP_REQUIRE(X && C_inout && labels_out && ws, "mtp_lloyd: null pointer");
+    MTP_REQUIRE(n >= k && k >= 1 && d >= 1 && max_iter >= 1, "mtp_lloyd: bad shape n=%lld k=%d d=%d max_iter=%d",
+                (long long)n, k, d, max_iter);
+    LloydWs w = carve_lloyd(ws, k, d);
+    const size_t need = w.bytes + (size_t)n * 4;
+    if (ws_bytes < need) {
+        mtp_set_error("mtp_lloyd: workspace of %zu bytes, need %zu", ws_bytes, need);
+        return MTP_E_WORKSPACE;
+    }
+    float *dist_scratch = reinterpret_cast<float *>(static_cast<char *>(ws) + w.bytes);
+    hipStream_t s = mtp_stream(stream);
+    if (check_every < 1) check_every = 1;
+
+    int rc = mtp_lloyd_begin_f32(C_inout, k, d, w.staged, w.c2, w.red, w.flags, stream);
+    if (rc != MTP_OK) return rc;
+    MTP_HIP(hipMemsetAsync(labels_out, 0xff, (size_t)n * 4, s));  // labels_old = -1 (_kmeans.py:685)
+
+    // centres ping-pong between C_inout (cur = 0) and the workspace copy (cur = 1)
+    float *cbuf[2] = {C_inout, w.c_alt};
+    int cur = 0;           // buffer holding the centres the next E-step reads
+    int enq_iters = 0;     // iterations enqueued so far
+    int32_t hflags[MTP_FLAG_WORDS];
+    for (;;) {
+        const int budget = (max_iter - enq_iters) < check_every ? (max_iter - enq_iters) : check_every;
+        for (int i = 0; i < budget; ++i) {
+            rc = mtp_lloyd_estep_f32(X, n, d, cbuf[cur], w.staged, w.c2, k, labels_out, w.red, w.flags, stream);
+            if (rc != MTP_OK) return rc;
+            rc = mtp_launch_mstep(w.red, cbuf[cur], cbuf[cur ^ 1], k, d, tol_abs, max_iter, 0, w.staged, w.c2, w.shift,
+                                  w.flags, s);
+            if (rc != MTP_OK) return rc;
+            cur ^= 1;
+            ++enq_iters;
+        }
+        MTP_HIP(hipMemcpyAsync(hflags, w.flags, sizeof(hflags), hipMemcpyDeviceToHost, s));
+        MTP_HIP(hipStreamSynchronize(s));
+        const int done_iters = hflags[MTP_FLAG_N_ITER];
+        if (hflags[MTP_FLAG_STATE] == MTP_STATE_RELOCATE) {
+            // iteration `done_iters` (0-based) stopped before its M-step: its E-step ran, labels and
+            // red are valid.  The centres it read are in parity (done_iters & 1).
+            const int old = done_iters & 1;
+            int m = hflags[MTP_FLAG_N_EMPTY];
+            if (m > MTP_MAX_RELOC) m = MTP_MAX_RELOC;
+            rc = mtp_far_points_f32(X, n, d, cbuf[old], labels_out, m, 0, w.far_val, w.far_idx, w.far_lab, w.far_rows,
+                                    dist_scratch, stream);
+            if (rc != MTP_OK) return rc;
+            rc = mtp_apply_relocation_f32(w.red, k, d, m, w.far_val, w.far_lab, w.far_rows, stream);
+            if (rc != MTP_OK) return rc;
+            MTP_HIP(hipMemsetAsync(w.flags + MTP_FLAG_STATE, 0, 4, s));
+            rc = mtp_launch_mstep(w.red, cbuf[old], cbuf[old ^ 1], k, d, tol_abs, max_iter, 1, w.staged, w.c2, w.shift,
+                                  w.flags, s);
+            if (rc != MTP_OK) return rc;
+            cur = old ^ 1;
+            enq_iters = done_iters + 1;
+            if (enq_iters < max_iter) continue;  // keep iterating (state decides below otherwise)
+            MTP_HIP(hipMemcpyAsync(hflags, w.flags, sizeof(hflags), hipMemcpyDeviceToHost, s));
+            MTP_HIP(hipStreamSynchronize(s));
+        }
+        if (hflags[MTP_FLAG_STATE] != MTP_STATE_RUNNING && hflags[MTP_FLAG_STATE] != MTP_STATE_RELOCATE) break;
+        if (enq_iters >= max_iter) break;  // cannot happen: the last M-step sets MAXITER
+    }
+    const int n_iter = hflags[MTP_FLAG_N_ITER];
+    const int fin = n_iter & 1;  // centres after n_iter M-steps live in parity n_iter & 1
+    if (hflags[MTP_FLAG_STATE] != MTP_STATE_STRICT) {
+        // rerun the E-step so that the labels match the final centres (_kmeans.py:736-748).
+        // staged / c2 already describe the final centres (written by the last M-step).
+        rc = mtp_launch_assign(X, n, d, cbuf[fin], w.staged, w.c2, k, labels_out, nullptr, nullptr, s);
+        if (rc != MTP_OK) return rc;
+    }
+    if (fin != 0) MTP_HIP(hipMemcpyAsync(C_inout, w.c_alt, (size_t)k * d * 4, hipMemcpyDeviceToDevice, s));
+    if (inertia_out != nullptr) {
+        MTP_HIP(hipMemsetAsync(inertia_out, 0, 8, s));
+        rc = mtp_launch_inertia(X, n, d, cbuf[fin], labels_out, inertia_out, nullptr, s);
+        if (rc != MTP_OK) return rc;
+    }
+    if (n_iter_out != nullptr) *n_iter_out = n_iter;
+    MTP_HIP(hipStreamSynchronize(s));
+    return MTP_OK;
+}

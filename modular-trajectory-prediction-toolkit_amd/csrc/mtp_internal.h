@@ -1,0 +1,104 @@
+// Internal declarations shared by the HIP translation units of libmtp_accel.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "mtp_accel.h"
+
+void mtp_set_error(const char *fmt, ...);
+
+#define MTP_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            mtp_set_error(__VA_ARGS__); \
+            return MTP_E_ARG;           \
+        }                               \
+    } while (0)
+
+#define MTP_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            mtp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MTP_E_HIP;                                                                      \
+        }                                                                                          \
+    } while (0)
+
+#define MTP_LAUNCH_CHECK() MTP_HIP(hipGetLastError())
+
+// ------------------------------------------------------------------------------------------
+// Staged centroid image (what the MFMA E-step streams through LDS).
+//
+// Centroids are grouped in tiles of 32 rows.  One tile image = 32*R 16-byte slots + 8 slots of
+// ||c||^2, R = d/4.  Row i's slot p = 2u + h holds the four floats C[i][8u + h + 2e], e=0..3:
+// the A operands of lane (i, h) for MFMA k-steps 4u..4u+3 (v_mfma_f32_32x32x2_f32 takes
+// k = 2s + h from lane half h at step s, so the dot product runs in natural k order).
+// Slot p of row i is stored at i*R + (p ^ swz(i)); the XOR makes the 16-lane groups of a
+// ds_read_b128 hit 16 distinct 16-byte bank slots for R % 16 == 0 and R % 16 == 8.
+// ------------------------------------------------------------------------------------------
+constexpr int MTP_CTW = 2;  // 32-centroid tiles per LDS stage
+
+__host__ __device__ inline bool mtp_mfma_dim(int d) { return d == 64 || d == 96 || d == 128; }
+__host__ __device__ inline int mtp_tile_floats(int d) { return 32 * d + 32; }
+__host__ __device__ inline int mtp_n_tiles(int k) { return ((k + 32 * MTP_CTW - 1) / (32 * MTP_CTW)) * MTP_CTW; }
+__host__ __device__ inline int mtp_swz(int i, int R) { return (R % 16 == 0) ? (i & 15) : ((i >> 1) & 7); }
+
+// The sklearn Lloyd "red" buffer layout: sums[k*d], counts[k], n_changed, spare
+__host__ __device__ inline int64_t mtp_red_len(int k, int d) { return (int64_t)k * d + k + 2; }
+
+static inline hipStream_t mtp_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- launchers implemented across the .hip files (all enqueue only) ----
+int mtp_launch_stage_centers(const float *C, int k, int d, float *staged, float *c2, const int32_t *state,
+                             hipStream_t s);
+int mtp_launch_assign(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2, int k,
+                      int32_t *labels, double *n_changed, const int32_t *state, hipStream_t s);
+int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,
+                          double *counts, const int32_t *state, hipStream_t s);
+int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
+                     int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, hipStream_t s);
+int mtp_launch_inertia(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
+                       float *per_point, hipStream_t s);
+
+// ||row||^2 in NumPy einsum("ij,ij->i") float order (see oracle.c orc_row_sqnorm_f32): four lane
+// accumulators, product rounded then added, blocks of 16 consumed vector 3,2,1,0, tail vectors in
+// order, (l0 + l1) + (l2 + l3).  Compiled with -ffp-contract=off so a*a + l stays two roundings.
+__device__ inline float mtp_sqnorm_einsum_order(const float *a, int d) {
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+    int e = 0;
+    for (; e + 16 <= d; e += 16) {
+        for (int v = 3; v >= 0; --v) {
+            const float *p = a + e + 4 * v;
+            l0 = l0 + p[0] * p[0];
+            l1 = l1 + p[1] * p[1];
+            l2 = l2 + p[2] * p[2];
+            l3 = l3 + p[3] * p[3];
+        }
+    }
+    for (; e < d; e += 4) {
+        l0 = l0 + a[e] * a[e];
+        if (e + 1 < d) l1 = l1 + a[e + 1] * a[e + 1];
+        if (e + 2 < d) l2 = l2 + a[e + 2] * a[e + 2];
+        if (e + 3 < d) l3 = l3 + a[e + 3] * a[e + 3];
+    }
+    return (l0 + l1) + (l2 + l3);
+}
+
+// Write one centroid row (values in `row`, LDS or global) into the staged image.  Called by a
+// whole block: thread t < R writes slot t.  j = global centroid index, valid = j < k.
+__device__ inline void mtp_write_staged_row(float *staged, int j, int d, const float *row, bool valid, float c2v,
+                                            int tid, int nthreads) {
+    const int R = d / 4;
+    const int tile = j >> 5, i = j & 31;
+    float *tb = staged + (size_t)tile * mtp_tile_floats(d);
+    for (int p = tid; p < R; p += nthreads) {
+        const int u = p >> 1, h = p & 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = make_float4(row[8 * u + h], row[8 * u + h + 2], row[8 * u + h + 4], row[8 * u + h + 6]);
+        reinterpret_cast<float4 *>(tb)[i * R + (p ^ mtp_swz(i, R))] = v;
+    }
+    if (tid == 0) tb[32 * d + i] = valid ? c2v : __builtin_inff();
+}

@@ -1,0 +1,616 @@
+// M-step of Lloyd's algorithm on gfx950 and the small kernels around it.
+//
+//   k_accumulate      segmented sum of member rows by label -> double sums / counts
+//                     (sklearn cluster/_k_means_lloyd.pyx:215-218,143-152; get_modality's gather,
+//                      PCCSNet/utils/utility.py:98-104).  HBM-bound: one pass over X.
+//   k_mstep_centers   average, centre shift, staged image + ||c||^2 of the new centres
+//   k_mstep_flags     convergence decision (sklearn cluster/_kmeans.py:715-734)
+//   k_inertia         sklearn cluster/_k_means_common.pyx:94-124
+//   k_col_*           KMeans.fit preprocessing (mean / variance / centring)
+//   k_point_dist, k_argmax_pass, k_apply_relocation   empty-cluster relocation
+//
+// Sums are accumulated in double (LDS ds_add_f64, then global_atomic_add_f64): the order of the
+// additions then changes the result only at the 1e-16 level, so centroids do not depend on the
+// workgroup schedule or on how many GPUs share the points.
+#include "mtp_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// k_accumulate.  grid = (n_chunks, n_ranges).  A workgroup owns clusters [k0, k0+kr) in LDS as
+// doubles and scans the labels of its row chunk; rows whose label is in range are fetched
+// (16 B per lane, LPR lanes per row, 64/LPR rows per wave instruction) and added in LDS.
+// LDS layout per cluster row: element 4c+e stored at e*(d/4) + c -> consecutive lanes hit
+// consecutive doubles for a fixed e.
+// ------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X, int64_t n, int d,
+                                                     const int32_t *__restrict__ labels, int k, int kr,
+                                                     int64_t rows_per_chunk, double *sums, double *counts,
+                                                     const int32_t *state) {
+    extern __shared__ __attribute__((aligned(16))) double acc[];  // kr*d doubles, then kr ints
+    if (state != nullptr && *state != MTP_STATE_RUNNING) return;
+    const int k0 = blockIdx.y * kr;
+    const int kn = min(kr, k - k0);
+    int *cnt = reinterpret_cast<int *>(acc + (size_t)kr * d);
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    for (int e = tid; e < kn * d; e += nthreads) acc[e] = 0.0;
+    for (int e = tid; e < kn; e += nthreads) cnt[e] = 0;
+    __syncthreads();
+
+    constexpr int RPW = 64 / LPR;  // rows per wave instruction
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int sub = lane / LPR, c0 = lane % LPR;
+    const int dq = d / 4;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_chunk;
+    const int64_t r_end = min(n, r_begin + rows_per_chunk);
+
+    for (int64_t base = r_begin + (int64_t)wave * 64; base < r_end; base += (int64_t)nwaves * 64) {
+        const int64_t myrow = base + lane;
+        int lab = -1;
+        if (myrow < r_end) lab = labels[myrow];
+        const int rel = lab - k0;
+        const bool hit = (rel >= 0) && (rel < kn);
+        unsigned long long m = __ballot(hit);
+        if (hit) atomicAdd(&cnt[rel], 1);
+        while (m) {
+            // up to 4 groups of RPW matching rows per trip: issue all row loads, then the LDS adds
+            int bsel[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int b = -1;
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) {
+                    const int bit = m ? (int)__builtin_ctzll(m) : -1;
+                    if (m) m &= m - 1;
+                    if (q == sub) b = bit;
+                }
+                bsel[g] = b;
+            }
+            float4 v[4];
+            int relsel[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                relsel[g] = __shfl(rel, bsel[g] < 0 ? 0 : bsel[g]);
+                v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bsel[g] >= 0 && c0 < dq) v[g] = reinterpret_cast<const float4 *>(X + (base + bsel[g]) * d)[c0];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (bsel[g] >= 0 && c0 < dq) {
+                    double *a = acc + (size_t)relsel[g] * d + c0;
+                    atomicAdd(a, (double)v[g].x);
+                    atomicAdd(a + dq, (double)v[g].y);
+                    atomicAdd(a + 2 * dq, (double)v[g].z);
+                    atomicAdd(a + 3 * dq, (double)v[g].w);
+                }
+            }
+            // rows wider than LPR*4 floats: remaining 16-byte chunks
+            for (int c = c0 + LPR; c < dq; c += LPR) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (bsel[g] >= 0) {
+                        const float4 w = reinterpret_cast<const float4 *>(X + (base + bsel[g]) * d)[c];
+                        double *a = acc + (size_t)relsel[g] * d + c;
+                        atomicAdd(a, (double)w.x);
+                        atomicAdd(a + dq, (double)w.y);
+                        atomicAdd(a + 2 * dq, (double)w.z);
+                        atomicAdd(a + 3 * dq, (double)w.w);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // flush: LDS element (row, e*dq + c) is column 4c+e
+    for (int idx = tid; idx < kn * d; idx += nthreads) {
+        const double v = acc[idx];
+        if (v != 0.0) {
+            const int row = idx / d, off = idx % d;
+            const int e = off / dq, c = off % dq;
+            atomicAdd(&sums[(size_t)(k0 + row) * d + 4 * c + e], v);
+        }
+    }
+    for (int idx = tid; idx < kn; idx += nthreads)
+        if (cnt[idx] != 0) atomicAdd(&counts[k0 + idx], (double)cnt[idx]);
+}
+
+// scalar fallback for d % 4 != 0 (known-answer tests): plain global double atomics
+__global__ __launch_bounds__(256) void k_accumulate_scalar(const float *__restrict__ X, int64_t n, int d,
+                                                           const int32_t *__restrict__ labels, int k, double *sums,
+                                                           double *counts, const int32_t *state) {
+    if (state != nullptr && *state != MTP_STATE_RUNNING) return;
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const int lab = labels[row];
+    if (lab < 0 || lab >= k) return;
+    atomicAdd(&counts[lab], 1.0);
+    for (int c = 0; c < d; ++c) atomicAdd(&sums[(size_t)lab * d + c], (double)X[row * d + c]);
+}
+
+static constexpr size_t ACC_LDS_BYTES = 152 * 1024;
+
+int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,
+                          double *counts, const int32_t *state, hipStream_t s) {
+    if (n == 0) return MTP_OK;
+    if (d % 4 != 0 || (size_t)d * 8 + 4 > ACC_LDS_BYTES) {
+        const int64_t blocks = (n + 255) / 256;
+        MTP_REQUIRE(blocks <= 0x7fffffff, "mtp_centroid_sums: n too large");
+        hipLaunchKernelGGL(k_accumulate_scalar, dim3((unsigned)blocks), dim3(256), 0, s, X, n, d, labels, k, sums,
+                           counts, state);
+        MTP_LAUNCH_CHECK();
+        return MTP_OK;
+    }
+    const int dq = d / 4;
+    int kr = (int)(ACC_LDS_BYTES / ((size_t)d * 8 + 4));
+    if (kr > k) kr = k;
+    const int n_ranges = (k + kr - 1) / kr;
+    kr = (k + n_ranges - 1) / n_ranges;  // balance the ranges
+    const size_t lds = (size_t)kr * d * 8 + (size_t)kr * 4;
+    // one workgroup per CU; a chunk must be worth its flush (kr*d doubles of atomics)
+    int64_t n_chunks = 256 / n_ranges;
+    const int64_t min_rows = (int64_t)8 * kr + 1024;
+    if (n_chunks > (n + min_rows - 1) / min_rows) n_chunks = (n + min_rows - 1) / min_rows;
+    if (n_chunks < 1) n_chunks = 1;
+    int64_t rows_per_chunk = (n + n_chunks - 1) / n_chunks;
+    rows_per_chunk = (rows_per_chunk + 63) / 64 * 64;
+    n_chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
+    const dim3 grid((unsigned)n_chunks, (unsigned)n_ranges);
+#define MTP_ACC_LAUNCH(LPR)                                                                                        \
+    do {                                                                                                           \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            MTP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate<LPR>),                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES + 1024));   \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL(k_accumulate<LPR>, grid, dim3(1024), lds, s, X, n, d, labels, k, kr, rows_per_chunk,    \
+                           sums, counts, state);                                                                   \
+    } while (0)
+    if (dq <= 8)
+        MTP_ACC_LAUNCH(8);
+    else if (dq <= 16)
+        MTP_ACC_LAUNCH(16);
+    else if (dq <= 32)
+        MTP_ACC_LAUNCH(32);
+    else
+        MTP_ACC_LAUNCH(64);
+#undef MTP_ACC_LAUNCH
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// M-step finish.  One block per cluster j (64 threads).  Every block first counts the empty
+// clusters itself (k doubles from L2) so that no extra launch is needed for the decision.
+// ------------------------------------------------------------------------------------------
+__device__ inline int block_count_empty(const double *counts, int k, int *scratch) {
+    int local = 0;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) local += (counts[j] == 0.0);
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[wave] = local;
+    __syncthreads();
+    int tot = 0;
+    for (int w = 0; w < nw; ++w) tot += scratch[w];
+    __syncthreads();
+    return tot;
+}
+
+// sklearn _k_means_common.pyx:16-43 (float): groups of four, ((t0+t1)+t2)+t3, then remainder.
+__device__ inline float euclid_sq_sklearn(const float *a, const float *b, int d) {
+    const int n4 = d / 4, rem = d % 4;
+    float result = 0.f;
+    for (int i = 0; i < n4; ++i) {
+        const float t0 = (a[0] - b[0]) * (a[0] - b[0]), t1 = (a[1] - b[1]) * (a[1] - b[1]);
+        const float t2 = (a[2] - b[2]) * (a[2] - b[2]), t3 = (a[3] - b[3]) * (a[3] - b[3]);
+        result += ((t0 + t1) + t2) + t3;
+        a += 4;
+        b += 4;
+    }
+    for (int i = 0; i < rem; ++i) result += (a[i] - b[i]) * (a[i] - b[i]);
+    return result;
+}
+
+__global__ __launch_bounds__(64) void k_mstep_centers(double *red, const float *__restrict__ C_old, float *C_new,
+                                                      int k, int d, int relocation_done, float *staged, float *c2,
+                                                      float *shift, const int32_t *flags) {
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // 2*d floats: new row, old row
+    __shared__ int scratch[2];
+    if (flags[MTP_FLAG_STATE] != MTP_STATE_RUNNING) return;
+    const double *counts = red + (size_t)k * d;
+    const int n_empty = block_count_empty(counts, k, scratch);
+    if (n_empty > 0 && !relocation_done) return;  // k_mstep_flags pauses the loop
+    const int j = blockIdx.x;
+    const bool valid = j < k;
+    float *rn = rowbuf, *ro = rowbuf + d;
+    __shared__ float c2s;
+    if (valid) {
+        // empty cluster after a declined relocation: sklearn copies the heaviest cluster's
+        // centre (_k_means_common.pyx:291-295); its averaged value is sums/count of that row.
+        int src = j;
+        if (counts[j] == 0.0) {
+            src = 0;
+            for (int q = 1; q < k; ++q)
+                if (counts[q] > counts[src]) src = q;
+        }
+        // (sklearn averages in place in index order, so a copy taken from a heavier cluster
+        // with a HIGHER index is that cluster's not-yet-averaged sum; reproduced as is.)
+        const float alpha = (src > j) ? 1.0f : 1.0f / (float)counts[src];
+        for (int c = threadIdx.x; c < d; c += 64) {
+            rn[c] = (float)red[(size_t)src * d + c] * alpha;
+            ro[c] = C_old[(size_t)j * d + c];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            c2s = mtp_sqnorm_einsum_order(rn, d);
+            c2[j] = c2s;
+            shift[j] = sqrtf(euclid_sq_sklearn(rn, ro, d));
+        }
+        for (int c = threadIdx.x; c < d; c += 64) C_new[(size_t)j * d + c] = rn[c];
+    }
+    __syncthreads();
+    if (staged != nullptr) mtp_write_staged_row(staged, j, d, rn, valid, valid ? c2s : 0.f, threadIdx.x, 64);
+}
+
+__global__ __launch_bounds__(256) void k_mstep_flags(double *red, int k, int d, double tol, int max_iter,
+                                                     int relocation_done, const float *shift, int32_t *flags) {
+    __shared__ int scratch[4];
+    __shared__ double dsum[4];
+    if (flags[MTP_FLAG_STATE] != MTP_STATE_RUNNING) return;
+    double *counts = red + (size_t)k * d;
+    const int n_empty = block_count_empty(counts, k, scratch);
+    if (n_empty > 0 && !relocation_done) {
+        if (threadIdx.x == 0) {
+            flags[MTP_FLAG_STATE] = MTP_STATE_RELOCATE;
+            flags[MTP_FLAG_N_EMPTY] = n_empty;
+        }
+        return;
+    }
+    // sum_j shift_j^2: squares in float like (center_shift**2), summed in double
+    double local = 0.0;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const float sh = shift[j];
+        local += (double)(sh * sh);
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0) dsum[threadIdx.x >> 6] = local;
+    __syncthreads();
+    const double n_changed = red[(size_t)k * d + k];
+    __syncthreads();
+    // zero the reduce buffer for the next iteration
+    const int64_t len = mtp_red_len(k, d);
+    for (int64_t e = threadIdx.x; e < len; e += blockDim.x) red[e] = 0.0;
+    if (threadIdx.x == 0) {
+        const double tot = dsum[0] + dsum[1] + dsum[2] + dsum[3];
+        const int it = flags[MTP_FLAG_N_ITER] + 1;
+        flags[MTP_FLAG_N_ITER] = it;
+        flags[MTP_FLAG_N_EMPTY] = 0;
+        int st = MTP_STATE_RUNNING;
+        if (n_changed == 0.0)
+            st = MTP_STATE_STRICT;
+        else if (tot <= tol)
+            st = MTP_STATE_TOL;
+        else if (it >= max_iter)
+            st = MTP_STATE_MAXITER;
+        flags[MTP_FLAG_STATE] = st;
+    }
+}
+
+int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
+                     int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, hipStream_t s) {
+    const bool mfma = mtp_mfma_dim(d);
+    const int rows = mfma ? mtp_n_tiles(k) * 32 : k;
+    hipLaunchKernelGGL(k_mstep_centers, dim3(rows), dim3(64), 2 * (size_t)d * sizeof(float), s, red, C_old, C_new, k, d,
+                       relocation_done, mfma ? staged : nullptr, c2, shift, flags);
+    MTP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mstep_flags, dim3(1), dim3(256), 0, s, red, k, d, tol, max_iter, relocation_done, shift,
+                       flags);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// get_modality finish: means = sums / counts, one rounding.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cluster_means(const double *sums, const double *counts, int k, int d,
+                                                       float *means, int32_t *n_empty) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (int64_t)k * d) {
+        const int j = (int)(e / d);
+        const double c = counts[j];
+        if (c > 0.0) means[e] = (float)(sums[e] / c);
+    }
+    if (n_empty != nullptr && e < k && counts[e] == 0.0) atomicAdd(n_empty, 1);
+}
+
+extern "C" int mtp_cluster_means_f32(const double *sums, const double *counts, int k, int d, float *means,
+                                     int32_t *n_empty_out, void *stream) {
+    MTP_REQUIRE(sums && counts && means && k > 0 && d > 0, "mtp_cluster_means: bad arguments");
+    hipStream_t s = mtp_stream(stream);
+    if (n_empty_out) MTP_HIP(hipMemsetAsync(n_empty_out, 0, sizeof(int32_t), s));
+    const int64_t tot = (int64_t)k * d;
+    hipLaunchKernelGGL(k_cluster_means, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, sums, counts, k, d, means,
+                       n_empty_out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Inertia and per-point distance to the assigned centre.  One point per LPR-lane group, 16 B
+// per lane; each lane's group-of-four term is sklearn's ((t0+t1)+t2)+t3 in float, the groups
+// and the points are then summed in double.
+// ------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void k_inertia(const float *__restrict__ X, int64_t n, int d,
+                                                 const float *__restrict__ C, const int32_t *__restrict__ labels,
+                                                 double *inertia, float *per_point) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane / LPR, c0 = lane % LPR;
+    const int dq = d / 4;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    double local = 0.0;
+    for (int64_t base = wave_id * RPW; base < n; base += n_waves * RPW) {
+        const int64_t row = base + sub;
+        double v = 0.0;
+        if (row < n) {
+            const float4 *xp = reinterpret_cast<const float4 *>(X + row * d);
+            const float4 *cp = reinterpret_cast<const float4 *>(C + (size_t)labels[row] * d);
+            for (int c = c0; c < dq; c += LPR) {
+                const float4 a = xp[c], b = cp[c];
+                const float t0 = (a.x - b.x) * (a.x - b.x), t1 = (a.y - b.y) * (a.y - b.y);
+                const float t2 = (a.z - b.z) * (a.z - b.z), t3 = (a.w - b.w) * (a.w - b.w);
+                v += (double)(((t0 + t1) + t2) + t3);
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (row < n && c0 == 0) {
+            if (per_point) per_point[row] = (float)v;
+            local += v;
+        }
+    }
+    if (inertia == nullptr) return;
+    __shared__ double part[4];
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if (lane == 0) part[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(inertia, part[0] + part[1] + part[2] + part[3]);
+}
+
+// d % 4 != 0: one thread per row, sklearn's exact float order
+__global__ __launch_bounds__(256) void k_inertia_scalar(const float *__restrict__ X, int64_t n, int d,
+                                                        const float *__restrict__ C,
+                                                        const int32_t *__restrict__ labels, double *inertia,
+                                                        float *per_point) {
+    double local = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
+        const float v = euclid_sq_sklearn(X + row * d, C + (size_t)labels[row] * d, d);
+        if (per_point) per_point[row] = v;
+        local += (double)v;
+    }
+    if (inertia == nullptr) return;
+    __shared__ double part[4];
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(inertia, part[0] + part[1] + part[2] + part[3]);
+}
+
+int mtp_launch_inertia(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
+                       float *per_point, hipStream_t s) {
+    if (n == 0) return MTP_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (d % 4 != 0) {
+        hipLaunchKernelGGL(k_inertia_scalar, grid, block, 0, s, X, n, d, C, labels, inertia, per_point);
+    } else if (d / 4 <= 8) {
+        hipLaunchKernelGGL(k_inertia<8>, grid, block, 0, s, X, n, d, C, labels, inertia, per_point);
+    } else if (d / 4 <= 16) {
+        hipLaunchKernelGGL(k_inertia<16>, grid, block, 0, s, X, n, d, C, labels, inertia, per_point);
+    } else {
+        hipLaunchKernelGGL(k_inertia<32>, grid, block, 0, s, X, n, d, C, labels, inertia, per_point);
+    }
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Column statistics / centring.  blockDim.x = d * rpb (rpb rows per pass), thread owns a column.
+// ------------------------------------------------------------------------------------------
+template <bool SQDEV>
+__global__ __launch_bounds__(1024) void k_col_stats(const float *__restrict__ X, int64_t n, int d, int rpb,
+                                                    int64_t rows_per_block, const double *__restrict__ mean,
+                                                    double *out) {
+    extern __shared__ __attribute__((aligned(16))) double part[];  // blockDim.x doubles
+    const int c = threadIdx.x % d, rslot = threadIdx.x / d;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = min(n, r_begin + rows_per_block);
+    const double mu = SQDEV ? mean[c] : 0.0;
+    double acc = 0.0;
+    for (int64_t r = r_begin + rslot; r < r_end; r += rpb) {
+        const double v = (double)X[r * d + c];
+        acc += SQDEV ? (v - mu) * (v - mu) : v;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (rslot == 0) {
+        for (int q = 1; q < rpb; ++q) acc += part[q * d + c];
+        atomicAdd(&out[c], acc);
+    }
+}
+
+static int launch_col_stats(bool sqdev, const float *X, int64_t n, int d, const double *mean, double *out,
+                            hipStream_t s) {
+    MTP_REQUIRE(d >= 1 && d <= 1024, "mtp_col_*: d must be in [1, 1024] (got %d)", d);
+    if (n == 0) return MTP_OK;
+    const int rpb = (256 / d) > 0 ? (256 / d) : 1;
+    const int threads = d * rpb;
+    int64_t blocks = (n + 511) / 512;
+    if (blocks > 2048) blocks = 2048;
+    const int64_t rows_per_block = (n + blocks - 1) / blocks;
+    blocks = (n + rows_per_block - 1) / rows_per_block;
+    const size_t lds = (size_t)threads * sizeof(double);
+    if (sqdev)
+        hipLaunchKernelGGL(k_col_stats<true>, dim3((unsigned)blocks), dim3(threads), lds, s, X, n, d, rpb, rows_per_block,
+                           mean, out);
+    else
+        hipLaunchKernelGGL(k_col_stats<false>, dim3((unsigned)blocks), dim3(threads), lds, s, X, n, d, rpb,
+                           rows_per_block, mean, out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+extern "C" int mtp_col_sums_f32(const float *X, int64_t n, int d, double *col_sum, void *stream) {
+    MTP_REQUIRE(X && col_sum, "mtp_col_sums: null pointer");
+    return launch_col_stats(false, X, n, d, nullptr, col_sum, mtp_stream(stream));
+}
+
+extern "C" int mtp_col_sqdev_f32(const float *X, int64_t n, int d, const double *mean, double *col_sqdev,
+                                 void *stream) {
+    MTP_REQUIRE(X && mean && col_sqdev, "mtp_col_sqdev: null pointer");
+    return launch_col_stats(true, X, n, d, mean, col_sqdev, mtp_stream(stream));
+}
+
+__global__ __launch_bounds__(256) void k_sub_rowvec(float *X, int64_t total, int d, const float *__restrict__ vec) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+        X[e] = X[e] - vec[e % d];
+}
+
+extern "C" int mtp_sub_rowvec_f32(float *X, int64_t n, int d, const float *vec, void *stream) {
+    MTP_REQUIRE(X && vec && d > 0, "mtp_sub_rowvec: bad arguments");
+    if (n == 0) return MTP_OK;
+    const int64_t total = n * d;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_sub_rowvec, dim3((unsigned)blocks), dim3(256), 0, mtp_stream(stream), X, total, d, vec);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+__global__ __launch_bounds__(256) void k_row_sqnorm(const float *__restrict__ A, int64_t n, int d, float *out) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < n) out[row] = mtp_sqnorm_einsum_order(A + row * d, d);
+}
+
+extern "C" int mtp_row_sqnorm_f32(const float *A, int64_t n, int d, float *out, void *stream) {
+    MTP_REQUIRE(A && out && d > 0, "mtp_row_sqnorm: bad arguments");
+    if (n == 0) return MTP_OK;
+    hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mtp_stream(stream), A, n, d, out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Empty-cluster relocation (sklearn _k_means_common.pyx:167-211).
+// distances = ((X - C_old[labels])**2).sum(axis=1) is NumPy float arithmetic there (pairwise
+// row sums); here the sklearn-grouped float form of k_inertia is used -- the same quantity
+// within a few ulp, only its ranking matters.  The m farthest points are selected by m argmax
+// passes (descending distance, ties to the lowest index); a selected point's distance is then
+// set to -1 so that the next pass skips it.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_argmax_pass(float *dist, int64_t n, int pass, const float *__restrict__ X,
+                                                      int d, const int32_t *__restrict__ labels, int64_t idx_offset,
+                                                      float *far_val, int64_t *far_idx, int32_t *far_lab,
+                                                      float *far_rows) {
+    __shared__ float sv[16];
+    __shared__ long long si[16];
+    float bv = -2.f;
+    long long bi = -1;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = dist[i];
+        if (v > bv) {
+            bv = v;
+            bi = i;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const long long oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sv[threadIdx.x >> 6] = bv;
+        si[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    __shared__ long long win;
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            if (sv[w] > bv || (sv[w] == bv && si[w] >= 0 && (bi < 0 || si[w] < bi))) {
+                bv = sv[w];
+                bi = si[w];
+            }
+        }
+        win = bi;
+        far_val[pass] = bi >= 0 ? bv : -1.f;
+        far_idx[pass] = bi >= 0 ? bi + idx_offset : -1;
+        far_lab[pass] = bi >= 0 ? labels[bi] : -1;
+        if (bi >= 0) dist[bi] = -1.f;
+    }
+    __syncthreads();
+    const long long w = win;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) far_rows[(size_t)pass * d + c] = w >= 0 ? X[w * d + c] : 0.f;
+}
+
+extern "C" int mtp_far_points_f32(const float *X, int64_t n, int d, const float *C_old, const int32_t *labels, int m,
+                                  int64_t idx_offset, float *far_val, int64_t *far_idx, int32_t *far_lab,
+                                  float *far_rows, float *dist_scratch, void *stream) {
+    MTP_REQUIRE(X && C_old && labels && far_val && far_idx && far_lab && far_rows && dist_scratch && m > 0 && d > 0,
+                "mtp_far_points: bad arguments");
+    hipStream_t s = mtp_stream(stream);
+    int rc = mtp_launch_inertia(X, n, d, C_old, labels, nullptr, dist_scratch, s);
+    if (rc != MTP_OK) return rc;
+    for (int p = 0; p < m; ++p) {
+        hipLaunchKernelGGL(k_argmax_pass, dim3(1), dim3(1024), 0, s, dist_scratch, n, p, X, d, labels, idx_offset,
+                           far_val, far_idx, far_lab, far_rows);
+        MTP_LAUNCH_CHECK();
+    }
+    return MTP_OK;
+}
+
+__global__ __launch_bounds__(256) void k_apply_relocation(double *red, int k, int d, int m,
+                                                          const float *__restrict__ far_val,
+                                                          const int32_t *__restrict__ far_lab,
+                                                          const float *__restrict__ far_rows) {
+    // single block; sequential over the empty clusters like the reference loop (:197-211)
+    if (!(far_val[0] > 0.f)) return;  // np.max(distances) == 0: relocating is pointless
+    double *counts = red + (size_t)k * d;
+    __shared__ int empties[1024];
+    __shared__ int n_empty;
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int j = 0; j < k && c < 1024; ++j)
+            if (counts[j] == 0.0) empties[c++] = j;
+        n_empty = c;
+    }
+    __syncthreads();
+    const int cnt = min(n_empty, m);
+    for (int i = 0; i < cnt; ++i) {
+        const int new_id = empties[i], old_id = far_lab[i];
+        if (old_id < 0) break;
+        for (int c = threadIdx.x; c < d; c += blockDim.x) {
+            const double x = (double)far_rows[(size_t)i * d + c];
+            red[(size_t)old_id * d + c] -= x;
+            red[(size_t)new_id * d + c] = x;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            counts[new_id] = 1.0;
+            counts[old_id] -= 1.0;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int mtp_apply_relocation_f32(double *red, int k, int d, int m, const float *far_val, const int32_t *far_lab,
+                                        const float *far_rows, void *stream) {
+    MTP_REQUIRE(red && far_val && far_lab && far_rows && m > 0 && m <= 1024, "mtp_apply_relocation: bad arguments");
+    hipLaunchKernelGGL(k_apply_relocation, dim3(1), dim3(256), 0, mtp_stream(stream), red, k, d, m, far_val, far_lab,
+                       far_rows);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}

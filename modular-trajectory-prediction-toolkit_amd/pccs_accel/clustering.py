@@ -1,0 +1,200 @@
+"""Modality clustering on MI355X: the host side of the reference's k-means call sites.
+
+Mirrors (same names, argument meaning and error behaviour)
+    PCCSNet/utils/utility.py:64-133   get_memory_data, get_modality, cluster_data, k_means_cluster
+    MomentaryPrediction/PCCSNet_XOE/utils/utility.py:67-144 (same + ``pm`` scaling, ``reC``)
+and the scikit-learn driver those call, ``KMeans(n_clusters, n_init=20).fit`` (sklearn 1.7.2,
+cluster/_kmeans.py:1427-1554), restated in ``kmeans_fit``.  All arithmetic on the points runs
+in the HIP kernels of libmtp_accel.so; this file only sequences them.
+"""
+import copy
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import seeding
+from .checkings import check_cluster_consistency, check_memory_consistency
+
+
+class ConvergenceWarning(UserWarning):
+    """Same role as sklearn.exceptions.ConvergenceWarning (fewer distinct clusters than asked)."""
+
+
+def _as_device_f32(data, device=None):
+    """Accept np.ndarray / torch tensor / array-like; return a float32 device tensor (a copy)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if isinstance(data, torch.Tensor):
+        t = data
+    else:
+        if not isinstance(data, np.ndarray):
+            data = np.array(data).astype(float)  # PCCSNet/utils/utility.py:109-110
+        t = torch.from_numpy(np.ascontiguousarray(data))
+    if t.dtype == torch.float64:
+        warnings.warn("pccs_accel clusters in float32 (the reference's practical dtype); float64 input is cast",
+                      RuntimeWarning, stacklevel=3)
+    if t.dim() != 2:
+        raise ValueError(f"Expected 2D array, got shape {tuple(t.shape)}")
+    return t.to(device=device, dtype=torch.float32, copy=True).contiguous()
+
+
+def tolerance_and_mean(X, tol):
+    """(tol_abs, mean32) as KMeans.fit computes them before centring
+    (sklearn cluster/_kmeans.py:279-287, :1478-1481): column means and variances, in double."""
+    n = X.shape[0]
+    col_sum = K.col_sums(X)
+    mean64 = col_sum / n
+    sqdev = K.col_sqdev(X, mean64)
+    tol_abs = float((sqdev / n).mean().item()) * tol if tol != 0 else 0.0
+    return tol_abs, mean64.to(torch.float32)
+
+
+def is_same_clustering(l1, l2, k):
+    """sklearn cluster/_k_means_common.pyx:314-328: l1 -> l2 is a function (device check)."""
+    pairs = l1.to(torch.int64) * k + l2.to(torch.int64)
+    return torch.unique(pairs).numel() == torch.unique(l1).numel()
+
+
+def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, max_iter=300, tol=1e-4,
+               x_mean=None, check_every=None):
+    """sklearn ``KMeans(n_clusters, n_init=n_init, init=init).fit(X)`` on one MI355X.
+
+    X: float32 device tensor [N, D] (not modified).  ``init``: 'k-means++' or a [K, D] array /
+    tensor of initial centres (then one run, like sklearn).  ``random_state``: None (NumPy's
+    global RandomState, so ``np.random.seed(s)`` before the call pins it, as with the
+    reference), an int, or a RandomState.  ``x_mean`` overrides the column mean (tests).
+    Returns dict(labels int32 [N] (device), centers float32 [K, D] (device), inertia, n_iter).
+    """
+    if not (isinstance(X, torch.Tensor) and X.is_cuda and X.dtype == torch.float32 and X.dim() == 2):
+        raise TypeError("kmeans_fit expects a float32 HIP device tensor [N, D]")
+    n, d = X.shape
+    if n < n_clusters:
+        raise ValueError(f"n_samples={n} should be >= n_clusters={n_clusters}.")
+    if random_state is None:
+        rs = np.random.mtrand._rand
+    elif isinstance(random_state, (int, np.integer)):
+        rs = np.random.RandomState(random_state)
+    else:
+        rs = random_state
+
+    X = X.contiguous()
+    tol_abs, mean32 = tolerance_and_mean(X, tol)
+    if x_mean is not None:
+        mean32 = torch.as_tensor(x_mean, dtype=torch.float32, device=X.device).contiguous()
+    Xc = X.clone()
+    K.sub_rowvec_(Xc, mean32)
+
+    init_is_array = not isinstance(init, str)
+    if init_is_array:
+        c_init = torch.as_tensor(init, device=X.device).to(torch.float32).clone().contiguous()
+        if tuple(c_init.shape) != (n_clusters, d):
+            raise ValueError(f"The shape of the initial centers {tuple(c_init.shape)} does not match "
+                             f"the number of clusters {n_clusters} / features {d}.")
+        if n_init != 1:
+            warnings.warn("Explicit initial center position passed: performing only one init", RuntimeWarning,
+                          stacklevel=2)
+        n_init = 1
+        K.sub_rowvec_(c_init, mean32)
+    elif init != "k-means++":
+        raise ValueError(f"init must be 'k-means++' or an array, got {init!r}")
+
+    best = None
+    for _ in range(n_init):
+        c0 = c_init if init_is_array else seeding.kmeans_plusplus(Xc, n_clusters, rs)[0]
+        labels, inertia, centers, n_iter = K.lloyd(Xc, c0, max_iter=max_iter, tol_abs=tol_abs, check_every=check_every)
+        if best is None or (inertia < best["inertia"] and not is_same_clustering(labels, best["labels"], n_clusters)):
+            best = dict(labels=labels, centers=centers, inertia=inertia, n_iter=n_iter)
+
+    best["centers"] = best["centers"] + mean32
+    distinct = int(torch.unique(best["labels"]).numel())
+    if distinct < n_clusters:
+        warnings.warn(f"Number of distinct clusters ({distinct}) found smaller than n_clusters ({n_clusters}). "
+                      "Possibly due to duplicate points in X.", ConvergenceWarning, stacklevel=2)
+    best["tol_abs"] = tol_abs
+    return best
+
+
+# ------------------------------------------------------------------------------------------
+# The reference's call sites
+# ------------------------------------------------------------------------------------------
+def k_means_cluster(data, n_clusters, init=20):
+    """PCCSNet/utils/utility.py:120-133.  ``init`` is sklearn's n_init.
+
+    Returns (cluster_result np.int32 [N], size_array np.int64 [K]); raises KeyError(i) when
+    cluster i ends up empty, as the reference's ``res[i]`` lookup does."""
+    X = _as_device_f32(data)
+    fit = kmeans_fit(X, n_clusters, n_init=init)
+    labels = fit["labels"]
+    sizes = torch.bincount(labels.to(torch.int64), minlength=n_clusters).cpu().numpy().astype(np.int64)
+    for i in range(n_clusters):
+        if sizes[i] == 0:
+            raise KeyError(i)
+    return labels.cpu().numpy(), sizes
+
+
+def cluster_data(data, n_cluster=200, save_dir=None, args=None):
+    """PCCSNet/utils/utility.py:108-117; with ``args`` the XOE variant
+    (PCCSNet_XOE/utils/utility.py:115-128): ``data[:, :args.obs_feat_size] *= args.pm`` first."""
+    if not isinstance(data, (np.ndarray, torch.Tensor)):
+        data = np.array(data).astype(float)
+    if args is not None:
+        print("pm %.4f Applied" % args.pm)
+        data[:, :args.obs_feat_size] *= args.pm
+    cluster_result, size_array = k_means_cluster(data, n_cluster)
+    if save_dir is not None:
+        np.save(os.path.join(save_dir, "cluster_result.npy"), cluster_result)
+        np.save(os.path.join(save_dir, "size_array.npy"), size_array)
+    return cluster_result, size_array
+
+
+def get_memory_data(dataset, save_dir, args):
+    """PCCSNet/utils/utility.py:64-85 (and the XOE copy, :67-92, when ``args`` has reC / pm)."""
+    mem_path = os.path.join(save_dir, "memory.npy")
+    if os.path.exists(mem_path) and check_memory_consistency(save_dir, args):
+        memory_data = np.load(mem_path)
+    else:
+        print("==> Generating Memory...")
+        memory_data = torch.cat([dataset.obs_enc, dataset.pred_enc], dim=1)
+        memory_data = memory_data.cpu().numpy()
+        np.save(mem_path, memory_data)
+
+    print("==> Memory Shape", memory_data.shape)
+
+    xoe = hasattr(args, "reC")
+    try:
+        cluster_result = np.load(os.path.join(save_dir, "cluster_result.npy"))
+        size_array = np.load(os.path.join(save_dir, "size_array.npy"))
+        if not check_cluster_consistency(save_dir, size_array, args):
+            raise FileNotFoundError
+        if xoe and args.reC:
+            raise FileNotFoundError
+    except FileNotFoundError:
+        if xoe:
+            args.reC = False
+        print("==> Clustering Memory...")
+        cluster_result, size_array = cluster_data(copy.deepcopy(memory_data), n_cluster=args.n_cluster,
+                                                  save_dir=save_dir, args=args if xoe else None)
+    return memory_data, cluster_result, size_array
+
+
+def get_modality(memory_data, cluster_result, num_cluster):
+    """PCCSNet/utils/utility.py:98-105: per-cluster mean of the member rows -> float32 [K, D].
+
+    ``memory_data`` may live on the CPU (as at train_steps.py:356) or on the GPU; the result is
+    returned on the input's device so the caller's ``.cuda()`` keeps working.  Raises
+    KeyError(i) for an empty cluster like the reference's dict lookup."""
+    src_device = memory_data.device if isinstance(memory_data, torch.Tensor) else torch.device("cpu")
+    X = _as_device_f32(memory_data)
+    labels = torch.as_tensor(np.asarray(cluster_result) if not isinstance(cluster_result, torch.Tensor)
+                             else cluster_result).to(device=X.device, dtype=torch.int32).contiguous()
+    if labels.numel() != X.shape[0]:
+        raise ValueError("cluster_result and memory_data disagree on the number of samples")
+    # labels outside [0, num_cluster) are ignored, as the reference's dict build ignores them
+    sums, counts = K.centroid_sums(X, labels, num_cluster)
+    means, n_empty = K.cluster_means(sums, counts)
+    if int(n_empty.item()) > 0:
+        raise KeyError(int(torch.nonzero(counts == 0)[0].item()))
+    return means.to(src_device)

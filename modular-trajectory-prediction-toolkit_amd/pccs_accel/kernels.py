@@ -1,0 +1,218 @@
+"""Torch-tensor front ends of the C-ABI entry points (one function per entry point).
+
+PyTorch is plumbing here: it owns device memory and the stream; every operation below is a
+hand-written HIP kernel reached through ctypes.  Shapes, dtypes, devices and contiguity are
+checked on the host before a kernel sees a pointer.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def _req(t, name, dtype, ndim=None, align=16):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise _lib.MtpError(f"{name}: pccs_accel kernels need a HIP device tensor (got device={t.device}); "
+                            "there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dimensions, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if t.numel() > 0 and t.data_ptr() % align != 0:
+        raise ValueError(f"{name}: storage must be {align}-byte aligned")
+    return t
+
+
+def staged_centers_floats(k, d):
+    return int(lib().mtp_staged_centers_floats(k, d))
+
+
+def row_sqnorm(A):
+    _req(A, "A", torch.float32, 2)
+    out = torch.empty(A.shape[0], dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        check(lib().mtp_row_sqnorm_f32(ptr(A), A.shape[0], A.shape[1], ptr(out), stream_ptr()), "mtp_row_sqnorm_f32")
+    return out
+
+
+def col_sums(X, out=None):
+    _req(X, "X", torch.float32, 2)
+    if out is None:
+        out = torch.zeros(X.shape[1], dtype=torch.float64, device=X.device)
+    _req(out, "out", torch.float64, 1)
+    with torch.cuda.device(X.device):
+        check(lib().mtp_col_sums_f32(ptr(X), X.shape[0], X.shape[1], ptr(out), stream_ptr()), "mtp_col_sums_f32")
+    return out
+
+
+def col_sqdev(X, mean64, out=None):
+    _req(X, "X", torch.float32, 2)
+    _req(mean64, "mean", torch.float64, 1)
+    assert mean64.numel() == X.shape[1]
+    if out is None:
+        out = torch.zeros(X.shape[1], dtype=torch.float64, device=X.device)
+    with torch.cuda.device(X.device):
+        check(lib().mtp_col_sqdev_f32(ptr(X), X.shape[0], X.shape[1], ptr(mean64), ptr(out), stream_ptr()),
+              "mtp_col_sqdev_f32")
+    return out
+
+
+def sub_rowvec_(X, vec):
+    _req(X, "X", torch.float32, 2)
+    _req(vec, "vec", torch.float32, 1)
+    assert vec.numel() == X.shape[1]
+    with torch.cuda.device(X.device):
+        check(lib().mtp_sub_rowvec_f32(ptr(X), X.shape[0], X.shape[1], ptr(vec), stream_ptr()), "mtp_sub_rowvec_f32")
+    return X
+
+
+def assign(X, C, labels=None, n_changed=None):
+    """E-step.  labels (int32 [N]) is updated in place when given (previous labels in, new
+    labels out) and returned.  n_changed: optional float64 [1] tensor, incremented."""
+    _req(X, "X", torch.float32, 2)
+    _req(C, "C", torch.float32, 2)
+    n, d = X.shape
+    k = C.shape[0]
+    if C.shape[1] != d:
+        raise ValueError(f"C has {C.shape[1]} features, X has {d}")
+    if labels is None:
+        labels = torch.full((n,), -1, dtype=torch.int32, device=X.device)
+    _req(labels, "labels", torch.int32, 1)
+    assert labels.numel() == n
+    if n_changed is not None:
+        _req(n_changed, "n_changed", torch.float64, 1)
+    ws_bytes = int(lib().mtp_assign_workspace_bytes(k, d))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
+    with torch.cuda.device(X.device):
+        check(lib().mtp_assign_f32(ptr(X), n, d, ptr(C), k, None, ptr(labels), ptr(n_changed), ptr(ws), ws_bytes,
+                                   stream_ptr()), "mtp_assign_f32")
+    return labels
+
+
+def centroid_sums(X, labels, k, sums=None, counts=None):
+    """sums [k, d] float64 += member rows, counts [k] float64 += member counts."""
+    _req(X, "X", torch.float32, 2)
+    _req(labels, "labels", torch.int32, 1)
+    n, d = X.shape
+    assert labels.numel() == n
+    if sums is None:
+        sums = torch.zeros((k, d), dtype=torch.float64, device=X.device)
+    if counts is None:
+        counts = torch.zeros(k, dtype=torch.float64, device=X.device)
+    _req(sums, "sums", torch.float64, 2)
+    _req(counts, "counts", torch.float64, 1)
+    assert tuple(sums.shape) == (k, d) and counts.numel() == k
+    with torch.cuda.device(X.device):
+        check(lib().mtp_centroid_sums_f32(ptr(X), n, d, ptr(labels), k, ptr(sums), ptr(counts), stream_ptr()),
+              "mtp_centroid_sums_f32")
+    return sums, counts
+
+
+def cluster_means(sums, counts):
+    _req(sums, "sums", torch.float64, 2)
+    _req(counts, "counts", torch.float64, 1)
+    k, d = sums.shape
+    means = torch.zeros((k, d), dtype=torch.float32, device=sums.device)
+    n_empty = torch.zeros(1, dtype=torch.int32, device=sums.device)
+    with torch.cuda.device(sums.device):
+        check(lib().mtp_cluster_means_f32(ptr(sums), ptr(counts), k, d, ptr(means), ptr(n_empty), stream_ptr()),
+              "mtp_cluster_means_f32")
+    return means, n_empty
+
+
+def inertia(X, C, labels, per_point=False):
+    _req(X, "X", torch.float32, 2)
+    _req(C, "C", torch.float32, 2)
+    _req(labels, "labels", torch.int32, 1)
+    n, d = X.shape
+    assert C.shape[1] == d and labels.numel() == n
+    out = torch.zeros(1, dtype=torch.float64, device=X.device)
+    pp = torch.empty(n, dtype=torch.float32, device=X.device) if per_point else None
+    with torch.cuda.device(X.device):
+        check(lib().mtp_inertia_f32(ptr(X), n, d, ptr(C), ptr(labels), ptr(out), ptr(pp), stream_ptr()),
+              "mtp_inertia_f32")
+    return (out, pp) if per_point else out
+
+
+def lloyd(Xc, C0, max_iter=300, tol_abs=0.0, check_every=None):
+    """Single-GPU sklearn ``_kmeans_single_lloyd`` on centred data.
+
+    Returns (labels int32 [N], inertia float, centers float32 [K, D], n_iter)."""
+    _req(Xc, "X", torch.float32, 2)
+    _req(C0, "C0", torch.float32, 2)
+    n, d = Xc.shape
+    k = C0.shape[0]
+    if C0.shape[1] != d:
+        raise ValueError(f"C0 has {C0.shape[1]} features, X has {d}")
+    if n < k:
+        raise ValueError(f"n_samples={n} should be >= n_clusters={k}.")
+    if check_every is None:
+        # sync with the host rarely when an iteration is short, every iteration when it is long
+        check_every = 1 if float(n) * k * d > 2e10 else 8
+    C = C0.clone()
+    labels = torch.empty(n, dtype=torch.int32, device=Xc.device)
+    inert = torch.zeros(1, dtype=torch.float64, device=Xc.device)
+    ws_bytes = int(lib().mtp_lloyd_workspace_bytes(k, d)) + n * 4
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Xc.device)
+    n_iter = ctypes.c_int(0)
+    with torch.cuda.device(Xc.device):
+        check(lib().mtp_lloyd_f32(ptr(Xc), n, d, ptr(C), k, int(max_iter), float(tol_abs), int(check_every),
+                                  ptr(labels), ptr(inert), ctypes.byref(n_iter), ptr(ws), ws_bytes, stream_ptr()),
+              "mtp_lloyd_f32")
+    return labels, float(inert.item()), C, int(n_iter.value)
+
+
+def best_of_k(pred, gt, mode=0, ade_div=None, best_of=None, want_per_agent=True):
+    """pred [N, Ktot, T, 2], gt [N, T, 2] (float32 or float64, same dtype).
+
+    Returns dict(min_ade, min_fde, idx, idx2 (per agent, or None), sums float64 [2] on device)."""
+    if pred.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"pred: expected float32 or float64, got {pred.dtype}")
+    _req(pred, "pred", pred.dtype, 4, align=pred.element_size())
+    _req(gt, "gt", pred.dtype, 3, align=pred.element_size())
+    n, ktot, t, two = pred.shape
+    if two != 2 or tuple(gt.shape) != (n, t, 2):
+        raise ValueError(f"shape mismatch: pred {tuple(pred.shape)}, gt {tuple(gt.shape)}")
+    k = ktot if best_of is None else int(best_of)
+    if not (1 <= k <= ktot):
+        raise ValueError(f"best_of={k} must be in [1, {ktot}]")
+    if mode not in (0, 1, 2):
+        raise ValueError(f"mode must be 0, 1 or 2 (got {mode})")
+    if ade_div is None:
+        ade_div = t
+    dev = pred.device
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    if want_per_agent:
+        min_ade = torch.empty(n, dtype=pred.dtype, device=dev)
+        min_fde = torch.empty(n, dtype=pred.dtype, device=dev)
+        idx = torch.empty(n, dtype=torch.int32, device=dev)
+        idx2 = torch.empty(n, dtype=torch.int32, device=dev)
+    else:
+        min_ade = min_fde = idx = idx2 = None
+    fn = lib().mtp_best_of_k_f32 if pred.dtype == torch.float32 else lib().mtp_best_of_k_f64
+    with torch.cuda.device(dev):
+        check(fn(ptr(pred), ptr(gt), n, k, ktot, t, float(ade_div), int(mode), ptr(min_ade), ptr(min_fde), ptr(idx),
+                 ptr(idx2), ptr(sums), stream_ptr()), "mtp_best_of_k")
+    return dict(min_ade=min_ade, min_fde=min_fde, idx=idx, idx2=idx2, sums=sums)
+
+
+def ade_fde(pred, gt, ade_div=1.0, best_of=None):
+    """Per-candidate (ADE, FDE) [N, K] for float32 pred [N, Ktot, T, 2], gt [N, T, 2]."""
+    _req(pred, "pred", torch.float32, 4, align=4)
+    _req(gt, "gt", torch.float32, 3, align=4)
+    n, ktot, t, two = pred.shape
+    if two != 2 or tuple(gt.shape) != (n, t, 2):
+        raise ValueError(f"shape mismatch: pred {tuple(pred.shape)}, gt {tuple(gt.shape)}")
+    k = ktot if best_of is None else int(best_of)
+    ade = torch.empty((n, k), dtype=torch.float32, device=pred.device)
+    fde = torch.empty((n, k), dtype=torch.float32, device=pred.device)
+    with torch.cuda.device(pred.device):
+        check(lib().mtp_ade_fde_f32(ptr(pred), ptr(gt), n, k, ktot, t, float(ade_div), ptr(ade), ptr(fde),
+                                    stream_ptr()), "mtp_ade_fde_f32")
+    return ade, fde

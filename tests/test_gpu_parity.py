@@ -1,0 +1,336 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle and the golden
+vectors generated from the reference.  Everything here is marked ``gpu``.
+
+Bars (north_star): integer outputs (labels, argmin indices, counts, n_iter) bit-exact --
+label mismatches are tolerated only where the float64-recomputed distance gap is < 1e-6
+relative, and are counted; centroids / inertia / ADE / FDE within 1e-5 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+import datagen
+import kmeans_oracle as O
+from conftest import G1_NAMES, g1_inputs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def dev(a, gpu_device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
+
+
+def assert_labels_match(X, C, got, want, allow_near_ties=True):
+    got = np.asarray(got)
+    want = np.asarray(want)
+    r = O.classify_label_mismatches(X, C, got, want)
+    if not allow_near_ties:
+        assert r["n_mismatch"] == 0, r
+    assert r["n_bad"] == 0, r
+    return r["n_mismatch"]
+
+
+# ------------------------------------------------------------------------------------------
+# E-step
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", G1_NAMES)
+def test_assign_bit_exact_vs_oracle_and_sklearn(name, gpu_device):
+    """MFMA E-step == oracle chain E-step == sklearn's first-iteration labels, bit for bit."""
+    from pccs_accel import kernels as K
+    g = load_golden(name)
+    X, C0 = g1_inputs(g)
+    xm = g["x_mean"]
+    Xc, Cc = X - xm, C0 - xm
+    labels = K.assign(dev(Xc, gpu_device), dev(Cc, gpu_device)).cpu().numpy()
+    assert labels.dtype == np.int32
+    want = O.assign(Xc, Cc, backend="chain")
+    assert np.array_equal(labels, want)
+    assert np.array_equal(labels, g["iter1_labels"])
+
+
+@pytest.mark.parametrize("n,d,k", [(1, 96, 1), (63, 96, 5), (257, 128, 33), (1000, 64, 70), (300, 8, 7),
+                                   (129, 2, 3), (500, 100, 40), (77, 7, 77)])
+def test_assign_ragged_shapes(n, d, k, gpu_device):
+    """Tail rows, K not a multiple of the 32-centroid tile, generic-kernel dims; n_changed."""
+    from pccs_accel import kernels as K
+    X = datagen.make_encodings(100 + n, n, d, max(1, k // 2), 1500, 700)
+    C = X[datagen.make_init_indices(7, n, k)].copy()
+    prev = torch.full((n,), -1, dtype=torch.int32, device=gpu_device)
+    n_changed = torch.zeros(1, dtype=torch.float64, device=gpu_device)
+    labels = K.assign(dev(X, gpu_device), dev(C, gpu_device), prev, n_changed).cpu().numpy()
+    want = O.assign(X, C, backend="chain")
+    assert np.array_equal(labels, want)
+    assert int(n_changed.item()) == n
+    # second call with the same centres: nothing changes
+    n_changed.zero_()
+    K.assign(dev(X, gpu_device), dev(C, gpu_device), prev, n_changed)
+    assert int(n_changed.item()) == 0
+
+
+def test_assign_exact_ties_take_lowest_index(gpu_device):
+    """Duplicate centroids: strict '<' keeps the first (sklearn _k_means_lloyd.pyx:205-213)."""
+    from pccs_accel import kernels as K
+    X = datagen.make_encodings(5, 512, 96, 6)
+    base = X[datagen.make_init_indices(9, 512, 40)].copy()
+    C = np.concatenate([base, base[::-1]], axis=0)  # every centre appears twice: j and 79-j
+    labels = K.assign(dev(X, gpu_device), dev(C, gpu_device)).cpu().numpy()
+    assert labels.max() < 40
+    assert np.array_equal(labels, O.assign(X, C, backend="chain"))
+
+
+def test_row_sqnorm_einsum_bits(gpu_device):
+    from pccs_accel import kernels as K
+    rs = np.random.RandomState(0)
+    for d in (1, 2, 5, 16, 17, 96, 100, 128):
+        A = (rs.randint(-4000, 4000, size=(300, d)) / 4096.0).astype(np.float32)
+        out = K.row_sqnorm(dev(A, gpu_device)).cpu().numpy()
+        assert np.array_equal(out, np.einsum("ij,ij->i", A, A)), d
+
+
+# ------------------------------------------------------------------------------------------
+# M-step pieces
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", G1_NAMES)
+def test_centroid_sums_and_get_modality(name, gpu_device):
+    from pccs_accel import kernels as K
+    from pccs_accel.utils.utility import get_modality
+    g = load_golden(name)
+    X, _ = g1_inputs(g)
+    k = int(g["K"])
+    labels = g["labels"]
+    sums, counts = K.centroid_sums(dev(X, gpu_device), dev(labels, gpu_device), k)
+    ws, wc = O.accumulate_f64(X, labels, k)
+    assert np.array_equal(counts.cpu().numpy(), wc)
+    assert np.allclose(sums.cpu().numpy(), ws, rtol=1e-12, atol=1e-12)
+    # drop-in get_modality: CPU tensor in (train_steps.py:356), float32 [K, D] out
+    mod = get_modality(torch.from_numpy(X), labels, k)
+    assert mod.dtype == torch.float32 and mod.device.type == "cpu"
+    assert np.allclose(mod.numpy(), g["modality"], rtol=RTOL, atol=1e-7)
+    assert np.allclose(mod.numpy(), O.get_modality(X, labels, k), rtol=1e-6, atol=1e-7)
+
+
+def test_get_modality_empty_cluster_keyerror(gpu_device):
+    from pccs_accel.utils.utility import get_modality
+    X = datagen.make_encodings(1, 64, 8, 2)
+    with pytest.raises(KeyError):
+        get_modality(torch.from_numpy(X), np.zeros(64, dtype=np.int32), 2)
+
+
+@pytest.mark.parametrize("n,d,k", [(1, 4, 1), (100, 12, 3), (5000, 96, 200), (3000, 128, 300), (999, 7, 5)])
+def test_centroid_sums_shapes(n, d, k, gpu_device):
+    """Ranges (K*D*8 > LDS), tiny inputs, d % 4 != 0 fallback."""
+    from pccs_accel import kernels as K
+    X = datagen.make_encodings(n + d, n, d, 3)
+    labels = np.random.RandomState(n).randint(0, k, size=n).astype(np.int32)
+    sums, counts = K.centroid_sums(dev(X, gpu_device), dev(labels, gpu_device), k)
+    ws, wc = O.accumulate_f64(X, labels, k)
+    assert np.array_equal(counts.cpu().numpy(), wc)
+    assert np.allclose(sums.cpu().numpy(), ws, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", G1_NAMES[:2])
+def test_inertia(name, gpu_device):
+    from pccs_accel import kernels as K
+    g = load_golden(name)
+    X, _ = g1_inputs(g)
+    v, pp = K.inertia(dev(X, gpu_device), dev(g["centers"], gpu_device), dev(g["labels"], gpu_device), per_point=True)
+    want, wpp = O.inertia(X, g["centers"], g["labels"], return_per_point=True)
+    assert np.isclose(v.item(), want, rtol=1e-6)
+    assert np.allclose(pp.cpu().numpy(), wpp, rtol=1e-5, atol=1e-9)
+    assert np.isclose(v.item(), float(g["inertia"]), rtol=RTOL)
+
+
+# ------------------------------------------------------------------------------------------
+# whole Lloyd runs
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", G1_NAMES)
+@pytest.mark.parametrize("check_every", [1, 8])
+def test_lloyd_fixed_init_vs_golden(name, check_every, gpu_device):
+    """_kmeans_single_lloyd on the centred data: n_iter, labels, centres, inertia."""
+    from pccs_accel import kernels as K
+    g = load_golden(name)
+    X, C0 = g1_inputs(g)
+    xm = g["x_mean"]
+    Xc = X - xm
+    labels, inertia, centers, n_iter = K.lloyd(dev(Xc, gpu_device), dev(C0 - xm, gpu_device), max_iter=300,
+                                               tol_abs=float(g["tol_abs"]), check_every=check_every)
+    assert n_iter == int(g["n_iter"])
+    centers = centers.cpu().numpy()
+    n_mis = assert_labels_match(Xc, centers, labels.cpu().numpy(), g["labels"])
+    assert n_mis == 0  # observed: bit-exact on every fixture
+    assert np.allclose(centers + xm, g["centers"], rtol=RTOL, atol=1e-6)
+    assert np.isclose(inertia, float(g["inertia"]), rtol=RTOL)
+    # and against the oracle run end to end
+    ol, oi, oc, on = O.kmeans_single_lloyd(Xc, C0 - xm, 300, float(g["tol_abs"]))
+    assert on == n_iter and np.array_equal(ol, labels.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", G1_NAMES)
+def test_kmeans_fit_fixed_init(name, gpu_device):
+    """KMeans(init=C0, n_init=1).fit including the device-side mean / tolerance."""
+    from pccs_accel.clustering import kmeans_fit
+    g = load_golden(name)
+    X, C0 = g1_inputs(g)
+    fit = kmeans_fit(dev(X, gpu_device), int(g["K"]), init=C0)
+    assert np.isclose(fit["tol_abs"], float(g["tol_abs"]), rtol=1e-5)
+    assert fit["n_iter"] == int(g["n_iter"])
+    centers = fit["centers"].cpu().numpy()
+    assert_labels_match(X, centers, fit["labels"].cpu().numpy(), g["labels"])
+    assert np.allclose(centers, g["centers"], rtol=RTOL, atol=1e-6)
+    assert np.isclose(fit["inertia"], float(g["inertia"]), rtol=RTOL)
+
+
+def test_max_iter_and_final_estep(gpu_device):
+    """max_iter hit before convergence: one more E-step makes labels match the final centres."""
+    from pccs_accel import kernels as K
+    g = load_golden("g1_hard_n5000_d96_k64")
+    X, C0 = g1_inputs(g)
+    xm = g["x_mean"]
+    Xc = X - xm
+    labels, inertia, centers, n_iter = K.lloyd(dev(Xc, gpu_device), dev(C0 - xm, gpu_device), max_iter=3,
+                                               tol_abs=float(g["tol_abs"]))
+    ol, oi, oc, on = O.kmeans_single_lloyd(Xc, C0 - xm, 3, float(g["tol_abs"]))
+    assert n_iter == on == 3
+    assert np.array_equal(labels.cpu().numpy(), ol)
+    assert np.allclose(centers.cpu().numpy(), oc, rtol=RTOL, atol=1e-6)
+    assert np.array_equal(labels.cpu().numpy(), O.assign(Xc, centers.cpu().numpy()))
+
+
+def test_kat_hand_computed_results(gpu_device):
+    """sklearn/cluster/tests/test_k_means.py:62-80 through the generic (d=2) kernels."""
+    from pccs_accel.clustering import kmeans_fit
+    g = load_golden("g5_kat_results")
+    fit = kmeans_fit(dev(g["X"], gpu_device), 2, init=g["init"])
+    assert list(fit["labels"].cpu().numpy()) == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert fit["n_iter"] == 2
+    assert np.allclose(fit["centers"].cpu().numpy(), [[0.125, 0], [0.875, 1]])
+    assert np.isclose(fit["inertia"], 0.375)
+
+
+def test_kat_relocated_clusters(gpu_device):
+    """sklearn/cluster/tests/test_k_means.py:85-111: an empty cluster is relocated onto the
+    farthest point (all four are equally far here; both outcomes are accepted by the KAT)."""
+    from pccs_accel.clustering import kmeans_fit
+    g = load_golden("g4_relocated_clusters")
+    fit = kmeans_fit(dev(g["X"].astype(np.float32), gpu_device), 2, init=g["init"].astype(np.float32))
+    labels = list(fit["labels"].cpu().numpy())
+    centers = fit["centers"].cpu().numpy()
+    assert fit["n_iter"] == 3 and np.isclose(fit["inertia"], 0.25)
+    ok_a = labels == [0, 0, 1, 1] and np.allclose(centers, [[0.25, 0], [0.75, 1]])
+    ok_b = labels == [1, 1, 0, 0] and np.allclose(centers, [[0.75, 1], [0.25, 0]])
+    assert ok_a or ok_b
+
+
+def test_relocation_on_mfma_path(gpu_device):
+    """A centre placed far away starts empty (d=96, MFMA path): it must be relocated onto the
+    point farthest from its centre, exactly as the oracle (== sklearn) does."""
+    from pccs_accel import kernels as K
+    X = datagen.make_encodings(77, 3000, 96, 10, 2000, 300)
+    xm = X.mean(axis=0)
+    Xc = X - xm
+    C0 = Xc[datagen.make_init_indices(78, 3000, 12)].copy()
+    C0[5] = 50.0  # nobody is closest to this one
+    tol = float(O.tolerance(X))
+    labels, inertia, centers, n_iter = K.lloyd(dev(Xc, gpu_device), dev(C0, gpu_device), tol_abs=tol)
+    ol, oi, oc, on = O.kmeans_single_lloyd(Xc, C0, 300, tol)
+    assert n_iter == on
+    assert_labels_match(Xc, oc, labels.cpu().numpy(), ol, allow_near_ties=False)
+    assert np.allclose(centers.cpu().numpy(), oc, rtol=RTOL, atol=1e-6)
+    assert len(np.unique(labels.cpu().numpy())) == 12
+
+
+# ------------------------------------------------------------------------------------------
+# ADE / FDE and best-of-K
+# ------------------------------------------------------------------------------------------
+def _g6_inputs(g):
+    pred, gt = datagen.make_trajectories(int(g["seed"]), int(g["n"]), int(g["k"]), int(g["t"]))
+    pred[5, 3] = gt[5] + np.float32(1.0 / 4096)
+    pred[5, 7] = pred[5, 3]
+    pred[9, 2, -1] = gt[9, -1]
+    pred[9, 11, -1] = gt[9, -1]
+    return pred, gt
+
+
+def test_metrics_dropin(gpu_device):
+    """displacement_error / final_displacement_error with the reference's calling patterns."""
+    from pccs_accel.utils.metrics import displacement_error, final_displacement_error
+    g = load_golden("g6_ade_fde")
+    pred, gt = _g6_inputs(g)
+    tp, tg = dev(pred, gpu_device), dev(gt, gpu_device)
+    t = int(g["t"])
+    for i in (0, 5, 9, 63):
+        A = displacement_error(tp[i], tg[i:i + 1]) / t          # train_steps.py:219
+        F = final_displacement_error(tp[i][:, -1], tg[i:i + 1][:, -1])  # train_steps.py:220
+        assert A.shape == (int(g["k"]),) and A.dtype == torch.float32 and A.is_cuda
+        assert np.allclose(A.cpu().numpy(), g["ade"][i], rtol=RTOL)
+        assert np.allclose(F.cpu().numpy(), g["fde"][i], rtol=RTOL)
+    assert np.isclose(displacement_error(tp[0], tg[0:1], mode="sum").item(), float(g["ade_sum0"]), rtol=RTOL)
+    assert np.isclose(final_displacement_error(tp[0][:, -1], tg[0:1][:, -1], mode="sum").item(),
+                      float(g["fde_sum0"]), rtol=RTOL)
+    # batch vs batch (train_steps.py:49-50), unknown mode -> None, shape mismatch -> AssertionError
+    full = displacement_error(tp[:, 0], tg).cpu().numpy()
+    assert np.allclose(full / t, g["ade"][:, 0], rtol=RTOL)
+    assert displacement_error(tp[0], tg[0:1], mode="other") is None
+    with pytest.raises(AssertionError):
+        displacement_error(tp[0][:, :5], tg[0:1])
+    with pytest.raises(Exception):
+        displacement_error(tp[0].cpu(), tg[0:1].cpu())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_best_of_k_modes_vs_golden(mode, gpu_device):
+    from pccs_accel.evaluation import best_of_k
+    g = load_golden("g6_ade_fde")
+    pred, gt = _g6_inputs(g)
+    min_ade, min_fde, idx, mean_ade, mean_fde = best_of_k(dev(pred, gpu_device), dev(gt, gpu_device), mode=mode)
+    assert np.array_equal(idx.cpu().numpy(), g[f"mode{mode}_idx"])  # incl. exact-tie agents 5 and 9
+    assert np.allclose(min_ade.cpu().numpy(), g[f"mode{mode}_mins"][:, 0], rtol=RTOL)
+    assert np.allclose(min_fde.cpu().numpy(), g[f"mode{mode}_mins"][:, 1], rtol=RTOL)
+    assert np.allclose([mean_ade, mean_fde], g[f"mode{mode}_val"], rtol=RTOL)
+    r = O.best_of_k(pred, gt, mode=mode)
+    assert np.array_equal(idx.cpu().numpy(), r["idx"])
+    assert np.allclose(min_ade.cpu().numpy(), r["min_ade"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("prio", ["adeprio", "fdeprio"])
+def test_verify_predictions_best_of_20_f64(prio, gpu_device):
+    """StimulusVerification/verify_predictions.py:238-248: float64, first 20 of 200 candidates."""
+    from pccs_accel.evaluation import best_of_k
+    g = load_golden("g7_verify_best_of_20")
+    pred, fut = datagen.make_trajectories(int(g["seed"]), int(g["n"]), int(g["ktot"]), int(g["t"]), dtype=np.float64)
+    n, t = int(g["n"]), int(g["t"])
+    _, _, idx, mean_ade, mean_fde = best_of_k(dev(pred, gpu_device), dev(fut, gpu_device),
+                                              mode=0 if prio == "adeprio" else 1, ade_div=1, best_of=int(g["best_of"]))
+    assert np.array_equal(idx.cpu().numpy(), g[prio + "_idx"])
+    assert np.isclose(mean_ade / t, float(g[prio + "_ade"]), rtol=1e-12)
+    assert np.isclose(mean_fde, float(g[prio + "_fde"]), rtol=1e-12)
+
+
+@pytest.mark.parametrize("n,k,t,dtype", [(1, 1, 1, np.float32), (3, 7, 5, np.float32), (1000, 100, 12, np.float32),
+                                         (257, 33, 12, np.float64), (40, 300, 3, np.float32)])
+def test_best_of_k_shapes(n, k, t, dtype, gpu_device):
+    """Odd T (scalar loads), K > 256, single agent / candidate; all three modes vs the oracle."""
+    from pccs_accel import kernels as K
+    pred, gt = datagen.make_trajectories(n * 7 + k, n, k, t, dtype=dtype)
+    for mode in (0, 1, 2):
+        r = K.best_of_k(dev(pred, gpu_device), dev(gt, gpu_device), mode=mode)
+        w = O.best_of_k(pred, gt, mode=mode)
+        assert np.array_equal(r["idx"].cpu().numpy(), w["idx"])
+        assert np.array_equal(r["idx2"].cpu().numpy(), w["idx2"])
+        assert np.allclose(r["min_ade"].cpu().numpy(), w["min_ade"], rtol=1e-6)
+        assert np.allclose(r["min_fde"].cpu().numpy(), w["min_fde"], rtol=1e-6)
+        assert np.allclose(r["sums"].cpu().numpy(), [w["sum_ade"], w["sum_fde"]], rtol=1e-9)
+
+
+def test_best_of_k_empty_and_bad_args(gpu_device):
+    from pccs_accel import kernels as K
+    pred = torch.zeros((0, 5, 12, 2), dtype=torch.float32, device=gpu_device)
+    gt = torch.zeros((0, 12, 2), dtype=torch.float32, device=gpu_device)
+    r = K.best_of_k(pred, gt)
+    assert r["idx"].numel() == 0 and r["sums"].cpu().tolist() == [0.0, 0.0]
+    with pytest.raises(ValueError):
+        K.best_of_k(torch.zeros((2, 5, 12, 2), device=gpu_device), torch.zeros((2, 11, 2), device=gpu_device))
+    with pytest.raises(ValueError):
+        K.best_of_k(torch.zeros((2, 5, 12, 2), device=gpu_device), torch.zeros((2, 12, 2), device=gpu_device), mode=3)
