@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the PCCSNet modality-clustering hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[3], the configuration the metric and the north-star target are
+quoted on): k-means over synthetic encodings, N = 10,000,000 points, D = 128, K = 1024, fixed
+init.  A "step" is one full Lloyd iteration over all N points: fused fp32-MFMA distance +
+argmin (E-step), double-accumulated centroid sums (M-step), [all-reduce of sums/counts over
+RCCL when N > 1], averaging / shift / convergence flags.  The N points are sharded over the
+ranks (strong scaling: total work fixed).  Convergence is disabled (tol < 0) so that exactly
+W + K iterations run; the run aborts if the loop stopped early.
+
+The JSON line also carries
+  roofline      for the dominant kernel (E-step): algorithmic 2*N*K*D flop / launch over its
+                average duration measured with events on the launch stream, against the fp32
+                matrix peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
+  cpu_baseline  the CPU oracle port (oracle/liboracle.so, OpenMP) timed on a bounded sample of
+                the same workload on this box's host cores (rank 0, N = 1 only);
+and, as extra keys, the M-step kernel's HBM rate, scikit-learn's own KMeans rate when it is
+importable (third-party package, not reference source), and the second half of the metric:
+best-of-K ADE/FDE trajectories/s on configs[4] (1M agents x K=100 x T=12).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "modular-trajectory-prediction-toolkit_amd"))
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md, HBM3E peak (spec); ~6300 achievable
+
+
+def make_encodings(n, d, k_true, seed, device):
+    """X = tanh(M[z] + 0.15*eps), M ~ N(0, 0.5^2) [k_true, d]; values in (-1, 1)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    gm = torch.Generator(device=device)
+    gm.manual_seed(0)  # the mixture is the same on every rank
+    M = torch.randn(k_true, d, generator=gm, device=device) * 0.5
+    X = torch.empty((n, d), dtype=torch.float32, device=device)
+    chunk = 1 << 20
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        z = torch.randint(0, k_true, (e - s,), generator=g, device=device)
+        X[s:e] = torch.tanh(M[z] + 0.15 * torch.randn(e - s, d, generator=g, device=device))
+    return X
+
+
+def make_trajectories(n, k, t, seed, device):
+    """gt = cumsum(N(0, 0.3^2)), pred = gt + N(0, 0.2^2)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    gt = torch.cumsum(torch.randn(n, t, 2, generator=g, device=device) * 0.3, dim=1).contiguous()
+    pred = torch.empty((n, k, t, 2), dtype=torch.float32, device=device)
+    chunk = 1 << 16
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        pred[s:e] = gt[s:e, None] + torch.randn(e - s, k, t, 2, generator=g, device=device) * 0.2
+    return pred, gt
+
+
+def cpu_baseline_kmeans(Xs, C0, k, d):
+    """One Lloyd iteration (E-step + M-step sums) of the CPU oracle port on a sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import kmeans_oracle as O
+    cores = int(O.lib().orc_num_threads())
+    c2 = O.row_sqnorm(C0)
+    t0 = time.perf_counter()
+    labels = O.assign(Xs, C0, c2, backend="chain")
+    O.accumulate(Xs, labels, k)
+    dt = time.perf_counter() - t0
+    out = {"value": Xs.shape[0] * k * d / dt, "unit": "distance-evals/s", "cores": cores, "kind": "port",
+           "sample": f"1 Lloyd iteration (oracle.c E-step, OpenMP, + M-step sums) on the first {Xs.shape[0]} "
+                     f"points of the workload, K={k}, D={d}; {dt:.2f} s",
+           "iters_per_s_full_n": None}
+    return out, labels
+
+
+def sklearn_baseline(Xs, C0, k, d):
+    try:
+        import warnings
+        from sklearn.cluster import KMeans
+        from threadpoolctl import threadpool_info
+    except Exception:  # noqa: BLE001
+        return None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t0 = time.perf_counter()
+        km = KMeans(n_clusters=k, init=C0, n_init=1, max_iter=2, tol=0).fit(Xs)
+        dt = time.perf_counter() - t0
+    threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    # 2 Lloyd iterations + the final E-step = 3 distance passes
+    return {"value": 3 * Xs.shape[0] * k * d / dt, "unit": "distance-evals/s", "threads": threads,
+            "sample": f"sklearn KMeans(init=C0, n_init=1, max_iter=2) on {Xs.shape[0]} points; {dt:.2f} s "
+                      f"({km.n_iter_} iterations + final E-step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--k", type=int, default=1024)
+    ap.add_argument("--eval-n", type=int, default=1_000_000)
+    ap.add_argument("--eval-k", type=int, default=100)
+    ap.add_argument("--eval-t", type=int, default=12)
+    ap.add_argument("--cpu-sample", type=int, default=5_000_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-eval", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from pccs_accel import dist as pdist
+    from pccs_accel import kernels as K
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n, d, k = args.n, args.d, args.k
+    lo, hi = pdist.shard_bounds(n, rank, world)
+    n_local = hi - lo
+    X = make_encodings(n_local, d, k, seed=1000 + rank, device=device)
+    # fixed init: K rows of rank 0's shard, the same on every rank
+    perm = torch.randperm(min(n_local, 1 << 22), generator=torch.Generator().manual_seed(3))[:k].to(device)
+    C0 = X[perm].contiguous()
+    if world > 1:
+        dist.broadcast(C0, src=0)
+    # centring as KMeans.fit does (global mean)
+    col = K.col_sums(X)
+    if world > 1:
+        dist.all_reduce(col)
+    mean32 = (col / n).to(torch.float32)
+    K.sub_rowvec_(X, mean32)
+    K.sub_rowvec_(C0, mean32)
+
+    sl = pdist.ShardedLloyd(X, C0, row_offset=lo)
+    TOL_NEVER = -1.0            # shift_tot <= tol never holds: no early exit inside the timed region
+    MAX_IT = 1 << 30
+    total_steps = args.warmup + args.steps
+
+    # every step ends with one flag read so that an empty cluster (they do occur in the first
+    # iterations of this workload) is relocated exactly as sklearn does; it is part of the step.
+    n_relocated = 0
+    for _ in range(args.warmup):
+        sl.assign()
+        sl.accumulate()
+        sl.reduce()
+        sl.mstep(TOL_NEVER, MAX_IT)
+        n_relocated += sl.finish_step(TOL_NEVER, MAX_IT)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        sl.assign()
+        ev[i][1].record()
+        sl.accumulate()
+        ev[i][2].record()
+        sl.reduce()
+        sl.mstep(TOL_NEVER, MAX_IT)
+        ev[i][3].record()
+        n_relocated += sl.finish_step(TOL_NEVER, MAX_IT)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    flags = sl.read_flags()
+    if int(flags[1]) != total_steps or int(flags[0]) != 0:
+        print(f"bench.py: Lloyd loop stopped early (state={flags[0]}, n_iter={flags[1]}, wanted {total_steps}); "
+              "timing invalid", file=sys.stderr)
+        sys.exit(3)
+
+    ms_assign = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    ms_accum = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    ms_rest = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+    ms_step = dt / args.steps * 1e3
+    evals_per_s = float(n) * k * d * args.steps / dt
+
+    # roofline of the dominant kernel, per launch, on this rank's shard
+    flop = 2.0 * n_local * k * d
+    achieved_tf = flop / (ms_assign * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "k_assign_mfma", "achieved": achieved_tf, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved_tf / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                "ms_per_launch": ms_assign, "algorithmic_flop_per_launch": flop}
+    acc_bytes = n_local * d * 4.0 + n_local * 4.0 + k * d * 8.0 + k * 8.0
+    roofline_update = {"bound": "hbm", "kernel": "k_accumulate", "achieved": acc_bytes / (ms_accum * 1e-3) / 1e9,
+                       "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": acc_bytes / (ms_accum * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                       "traffic": None, "ms_per_launch": ms_accum, "algorithmic_bytes_per_launch": acc_bytes}
+
+    out = {
+        "metric": "k-means iters/sec (N×K×D distance evals/sec) + best-of-K ADE/FDE traj/sec",
+        "value": evals_per_s, "unit": "distance-evals/s (N*K*D MACs of the cross term per second, whole job)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"k-means Lloyd iterations, synthetic encodings N={n} D={d} K={k}, fixed init, "
+                               f"points sharded over {world} GPU(s)" + (", RCCL all-reduce of sums/counts" if world > 1 else ""),
+                   "n": n, "d": d, "k": k, "parallelism": f"points/{world}"},
+        "iters_per_s": args.steps / dt, "clusters_relocated": n_relocated,
+        "ms_breakdown": {"assign": ms_assign, "accumulate": ms_accum, "allreduce+mstep": ms_rest},
+        "roofline": roofline, "roofline_update": roofline_update,
+    }
+
+    # ---- best-of-K ADE/FDE (second half of the metric), agents sharded, no exchange ----
+    if not args.no_eval:
+        del sl
+        elo, ehi = pdist.shard_bounds(args.eval_n, rank, world)
+        pred, gt = make_trajectories(ehi - elo, args.eval_k, args.eval_t, seed=4 + rank, device=device)
+        reps = 10
+        for _ in range(2):
+            K.best_of_k(pred, gt, mode=0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(reps):
+            r = K.best_of_k(pred, gt, mode=i % 3)
+        e1.record()
+        if world > 1:
+            dist.all_reduce(r["sums"])
+        barrier()
+        edt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([edt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            edt = float(tmax.item())
+        ms_eval = e0.elapsed_time(e1) / reps
+        ebytes = (ehi - elo) * (args.eval_k * args.eval_t * 2 * 4.0 + args.eval_t * 2 * 4.0 + 16.0)
+        out["best_of_k"] = {
+            "value": float(args.eval_n) * args.eval_k * reps / edt, "unit": "traj/s (candidate trajectories scored, whole job)",
+            "config": {"workload": f"best-of-K ADE/FDE, {args.eval_n} agents x K={args.eval_k} x T={args.eval_t}, modes 0/1/2"},
+            "ms_per_pass": edt / reps * 1e3,
+            "roofline": {"bound": "hbm", "kernel": "k_best_of_k", "achieved": ebytes / (ms_eval * 1e-3) / 1e9,
+                         "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ebytes / (ms_eval * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                         "traffic": None, "ms_per_launch": ms_eval, "algorithmic_bytes_per_launch": ebytes}}
+        del pred, gt
+
+    # ---- CPU baseline on a bounded sample (rank 0, N = 1 only) ----
+    if world == 1 and not args.no_cpu:
+        ns = min(args.cpu_sample, n_local)
+        Xs = X[:ns].cpu().numpy()
+        C0h = C0.cpu().numpy()
+        base, cpu_labels = cpu_baseline_kmeans(Xs, C0h, k, d)
+        base["iters_per_s_full_n"] = base["value"] / (float(n) * k * d)
+        out["cpu_baseline"] = base
+        # parity gate run with the benchmark: the GPU E-step on the same sample and centres
+        gl = K.assign(X[:ns].contiguous(), C0).cpu().numpy()
+        out["parity"] = {"sample_points": int(ns), "label_mismatches_vs_cpu_oracle": int((gl != cpu_labels).sum())}
+        sk = sklearn_baseline(Xs, C0h, k, d)
+        if sk is not None:
+            out["sklearn_baseline"] = sk
+    else:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

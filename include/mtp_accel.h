@@ -115,6 +115,13 @@ int mtp_lloyd_begin_f32(const float *C, int k, int d, float *staged, float *c2, 
 int mtp_lloyd_estep_f32(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2,
                         int k, int32_t *labels, double *red, const int32_t *flags, void *stream);
 
+/* The two halves of mtp_lloyd_estep_f32, separately launchable (bench.py brackets each with
+ * events): labels + n_changed only / local sums + counts only. */
+int mtp_lloyd_assign_f32(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2,
+                         int k, int32_t *labels, double *red, const int32_t *flags, void *stream);
+int mtp_lloyd_accumulate_f32(const float *X, int64_t n, int d, const int32_t *labels, int k, double *red,
+                             const int32_t *flags, void *stream);
+
 /* Finish the iteration from the (all-reduced) red buffer: average (alpha = 1/w, c *= alpha),
  * centre shift, strict / tol convergence (sklearn _k_means_common.pyx:274-311 and
  * _kmeans.py:715-734).  C_new, staged, c2, shift[k] are written, red is zeroed, flags updated.

@@ -112,13 +112,26 @@ extern "C" int mtp_lloyd_begin_f32(const float *C, int k, int d, float *staged, 
     return mtp_launch_stage_centers(C, k, d, staged, c2, nullptr, s);
 }
 
+extern "C" int mtp_lloyd_assign_f32(const float *X, int64_t n, int d, const float *C, const float *staged,
+                                    const float *c2, int k, int32_t *labels, double *red, const int32_t *flags,
+                                    void *stream) {
+    MTP_REQUIRE(X && C && c2 && labels && red && flags, "mtp_lloyd_assign: null pointer");
+    return mtp_launch_assign(X, n, d, C, staged, c2, k, labels, red + (size_t)k * d + k, flags + MTP_FLAG_STATE,
+                             mtp_stream(stream));
+}
+
+extern "C" int mtp_lloyd_accumulate_f32(const float *X, int64_t n, int d, const int32_t *labels, int k, double *red,
+                                        const int32_t *flags, void *stream) {
+    MTP_REQUIRE(X && labels && red && flags, "mtp_lloyd_accumulate: null pointer");
+    return mtp_launch_accumulate(X, n, d, labels, k, red, red + (size_t)k * d, flags + MTP_FLAG_STATE,
+                                 mtp_stream(stream));
+}
+
 extern "C" int mtp_lloyd_estep_f32(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2,
                                    int k, int32_t *labels, double *red, const int32_t *flags, void *stream) {
-    MTP_REQUIRE(X && C && c2 && labels && red && flags, "mtp_lloyd_estep: null pointer");
-    hipStream_t s = mtp_stream(stream);
-    int rc = mtp_launch_assign(X, n, d, C, staged, c2, k, labels, red + (size_t)k * d + k, flags + MTP_FLAG_STATE, s);
+    int rc = mtp_lloyd_assign_f32(X, n, d, C, staged, c2, k, labels, red, flags, stream);
     if (rc != MTP_OK) return rc;
-    return mtp_launch_accumulate(X, n, d, labels, k, red, red + (size_t)k * d, flags + MTP_FLAG_STATE, s);
+    return mtp_lloyd_accumulate_f32(X, n, d, labels, k, red, flags, stream);
 }
 
 extern "C" int mtp_lloyd_mstep_f32(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,

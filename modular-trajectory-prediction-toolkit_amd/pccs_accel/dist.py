@@ -1,0 +1,250 @@
+"""Points sharded over the GPUs of one node: one process per GPU, torch.distributed (RCCL).
+
+The E-step is embarrassingly parallel over points; the M-step needs exactly one exchange per
+Lloyd iteration: an all-reduce(sum) of the packed double buffer ``red`` = [K*D sums | K counts |
+n_changed | spare] (K=1024, D=128: 1.03 MB).  Every rank then finishes the iteration
+identically from the reduced buffer (average, centre shift, convergence flags), so centroids
+stay replicated bit-for-bit and no broadcast is needed.  Because the sums are doubles the
+result does not depend on how many ranks share the points.  Labels stay sharded.
+
+Empty-cluster relocation (rare) needs the globally farthest points: each rank offers its local
+top-m, the candidates are all-gathered and every rank picks the same global top-m.
+
+``ShardedLloyd`` also runs with world_size 1 (no collective), which is what bench.py times at
+N=1.  ``group``/``backend`` are whatever the caller initialised; the CPU tests drive the same
+class logic over gloo with a NumPy stand-in for the kernels (tests/test_dist_gloo.py).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import (FLAG_N_EMPTY, FLAG_N_ITER, FLAG_STATE, FLAG_WORDS, STATE_RELOCATE, STATE_RUNNING, STATE_STRICT,
+                   check, lib, ptr, stream_ptr)
+
+MAX_RELOC = 64
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n_total, rank, world_size):
+    """Contiguous row block of ``rank``: the first n_total % world_size ranks get one extra row."""
+    base, rem = divmod(n_total, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class DeviceOps:
+    """The HIP kernels behind the step-level C-ABI (include/mtp_accel.h)."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def zeros(self, n, dtype):
+        return torch.zeros(n, dtype=dtype, device=self.device)
+
+    def begin(self, C, k, d, staged, c2, red, flags):
+        check(lib().mtp_lloyd_begin_f32(ptr(C), k, d, ptr(staged), ptr(c2), ptr(red), ptr(flags), stream_ptr()),
+              "mtp_lloyd_begin_f32")
+
+    def assign(self, X, C, staged, c2, k, labels, red, flags):
+        n, d = X.shape
+        check(lib().mtp_lloyd_assign_f32(ptr(X), n, d, ptr(C), ptr(staged), ptr(c2), k, ptr(labels), ptr(red),
+                                         ptr(flags), stream_ptr()), "mtp_lloyd_assign_f32")
+
+    def accumulate(self, X, k, labels, red, flags):
+        n, d = X.shape
+        check(lib().mtp_lloyd_accumulate_f32(ptr(X), n, d, ptr(labels), k, ptr(red), ptr(flags), stream_ptr()),
+              "mtp_lloyd_accumulate_f32")
+
+    def mstep(self, red, C_old, C_new, k, d, tol, max_iter, relocation_done, staged, c2, shift, flags):
+        check(lib().mtp_lloyd_mstep_f32(ptr(red), ptr(C_old), ptr(C_new), k, d, float(tol), int(max_iter),
+                                        int(relocation_done), ptr(staged), ptr(c2), ptr(shift), ptr(flags),
+                                        stream_ptr()), "mtp_lloyd_mstep_f32")
+
+    def far_points(self, X, C_old, labels, m, idx_offset):
+        n, d = X.shape
+        val = torch.empty(m, dtype=torch.float32, device=self.device)
+        idx = torch.empty(m, dtype=torch.int64, device=self.device)
+        lab = torch.empty(m, dtype=torch.int32, device=self.device)
+        rows = torch.empty((m, d), dtype=torch.float32, device=self.device)
+        scratch = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        check(lib().mtp_far_points_f32(ptr(X), n, d, ptr(C_old), ptr(labels), m, int(idx_offset), ptr(val), ptr(idx),
+                                       ptr(lab), ptr(rows), ptr(scratch), stream_ptr()), "mtp_far_points_f32")
+        return val, idx, lab, rows
+
+    def apply_relocation(self, red, k, d, m, val, lab, rows):
+        check(lib().mtp_apply_relocation_f32(ptr(red), k, d, m, ptr(val), ptr(lab), ptr(rows), stream_ptr()),
+              "mtp_apply_relocation_f32")
+
+    def final_assign(self, X, C, staged, c2, k, labels):
+        # E-step only, ignoring the state word (labels must match the final centres)
+        n, d = X.shape
+        running = torch.zeros(FLAG_WORDS, dtype=torch.int32, device=self.device)
+        scratch = torch.zeros(k * d + k + 2, dtype=torch.float64, device=self.device)
+        check(lib().mtp_lloyd_assign_f32(ptr(X), n, d, ptr(C), ptr(staged), ptr(c2), k, ptr(labels), ptr(scratch),
+                                         ptr(running), stream_ptr()), "mtp_lloyd_assign_f32")
+
+    def inertia(self, X, C, labels):
+        from . import kernels as K
+        return K.inertia(X, C, labels)
+
+
+class ShardedLloyd:
+    """sklearn ``_kmeans_single_lloyd`` (cluster/_kmeans.py:624-752) over row-sharded points.
+
+    X_local: this rank's centred rows [n_local, D] (float32).  C0: initial centres [K, D],
+    identical on every rank.  ``row_offset``: global index of the first local row.
+    """
+
+    def __init__(self, X_local, C0, row_offset=0, group=None, ops=None):
+        self.X = X_local
+        self.n, self.d = X_local.shape
+        self.k = C0.shape[0]
+        self.group = group
+        self.rank, self.world = world()
+        self.row_offset = row_offset
+        self.ops = ops if ops is not None else DeviceOps(X_local.device)
+        o = self.ops
+        k, d = self.k, self.d
+        self.red = o.zeros(k * d + k + 2, torch.float64)
+        self.flags = o.zeros(FLAG_WORDS, torch.int32)
+        n_staged = int(lib().mtp_staged_centers_floats(k, d)) if ops is None else 0
+        self.staged = o.zeros(max(n_staged, 4), torch.float32)
+        self.c2 = o.zeros(k, torch.float32)
+        self.shift = o.zeros(k, torch.float32)
+        self.cbuf = [C0.clone().contiguous(), o.zeros(k * d, torch.float32).view(k, d)]
+        self.cur = 0
+        self.labels = (o.zeros(self.n, torch.int32) - 1).contiguous()
+        o.begin(self.cbuf[0], k, d, self.staged, self.c2, self.red, self.flags)
+
+    # -- one iteration, in the three pieces bench.py times separately --
+    def assign(self):
+        self.ops.assign(self.X, self.cbuf[self.cur], self.staged, self.c2, self.k, self.labels, self.red, self.flags)
+
+    def accumulate(self):
+        self.ops.accumulate(self.X, self.k, self.labels, self.red, self.flags)
+
+    def reduce(self):
+        if self.world > 1:
+            dist.all_reduce(self.red, op=dist.ReduceOp.SUM, group=self.group)
+
+    def mstep(self, tol, max_iter, relocation_done=0):
+        self.ops.mstep(self.red, self.cbuf[self.cur], self.cbuf[self.cur ^ 1], self.k, self.d, tol, max_iter,
+                       relocation_done, self.staged, self.c2, self.shift, self.flags)
+
+    def step(self, tol, max_iter):
+        self.assign()
+        self.accumulate()
+        self.reduce()
+        self.mstep(tol, max_iter)
+        self.cur ^= 1
+
+    def read_flags(self):
+        return self.flags.cpu().numpy()
+
+    def finish_step(self, tol, max_iter):
+        """After assign/accumulate/reduce/mstep of one iteration: read the flags (one host
+        sync) and, if the M-step paused on an empty cluster, relocate and redo it.  Returns the
+        number of clusters relocated (0 almost always)."""
+        f = self.read_flags()
+        n_reloc = 0
+        if f[FLAG_STATE] == STATE_RELOCATE:
+            n_reloc = int(f[FLAG_N_EMPTY])
+            self._relocate(n_reloc, self.cur)
+            self.flags[FLAG_STATE] = STATE_RUNNING
+            self.mstep(tol, max_iter, relocation_done=1)
+        self.cur ^= 1
+        return n_reloc
+
+    def _relocate(self, m, old):
+        """Global top-m farthest points -> apply to the (replicated) reduced buffer."""
+        o = self.ops
+        m = min(int(m), MAX_RELOC)
+        val, idx, lab, rows = o.far_points(self.X, self.cbuf[old], self.labels, m, self.row_offset)
+        if self.world > 1:
+            gv = [torch.empty_like(val) for _ in range(self.world)]
+            gi = [torch.empty_like(idx) for _ in range(self.world)]
+            gl = [torch.empty_like(lab) for _ in range(self.world)]
+            gr = [torch.empty_like(rows) for _ in range(self.world)]
+            dist.all_gather(gv, val, group=self.group)
+            dist.all_gather(gi, idx, group=self.group)
+            dist.all_gather(gl, lab, group=self.group)
+            dist.all_gather(gr, rows, group=self.group)
+            v = torch.cat(gv).cpu().numpy()
+            i = torch.cat(gi).cpu().numpy()
+            # descending distance, ties to the lowest global row index; ranks without rows offer -1
+            order = np.lexsort((i, -v))
+            order = np.array([q for q in order if i[q] >= 0][:m], dtype=np.int64)
+            sel = torch.from_numpy(order).to(val.device)
+            val, lab, rows = torch.cat(gv)[sel].contiguous(), torch.cat(gl)[sel].contiguous(), \
+                torch.cat(gr)[sel].contiguous()
+            if val.numel() < m:  # fewer points than empty clusters: pad with "no candidate"
+                pad = m - val.numel()
+                val = torch.cat([val, val.new_full((pad,), -1.0)])
+                lab = torch.cat([lab, lab.new_full((pad,), -1)])
+                rows = torch.cat([rows, rows.new_zeros((pad, self.d))])
+        o.apply_relocation(self.red, self.k, self.d, m, val, lab, rows)
+
+    def run(self, max_iter=300, tol_abs=0.0, check_every=1):
+        """Returns (labels_local int32, inertia (global), centers [K, D], n_iter)."""
+        enq = 0
+        while True:
+            budget = min(check_every, max_iter - enq)
+            for _ in range(budget):
+                self.step(tol_abs, max_iter)
+                enq += 1
+            f = self.read_flags()
+            done_iters = int(f[FLAG_N_ITER])
+            if f[FLAG_STATE] == STATE_RELOCATE:
+                old = done_iters & 1
+                self._relocate(f[FLAG_N_EMPTY], old)
+                self.flags[FLAG_STATE] = STATE_RUNNING
+                self.cur = old
+                self.mstep(tol_abs, max_iter, relocation_done=1)
+                self.cur = old ^ 1
+                enq = done_iters + 1
+                if enq < max_iter:
+                    continue
+                f = self.read_flags()
+            if f[FLAG_STATE] != STATE_RUNNING and f[FLAG_STATE] != STATE_RELOCATE:
+                break
+            if enq >= max_iter:
+                break
+        n_iter = int(f[FLAG_N_ITER])
+        fin = n_iter & 1
+        centers = self.cbuf[fin]
+        if f[FLAG_STATE] != STATE_STRICT:
+            self.ops.final_assign(self.X, centers, self.staged, self.c2, self.k, self.labels)
+        inertia = self.ops.inertia(self.X, centers, self.labels)
+        if self.world > 1:
+            dist.all_reduce(inertia, op=dist.ReduceOp.SUM, group=self.group)
+        return self.labels, float(inertia.item()), centers, n_iter
+
+
+def kmeans_fit_sharded(X_local, n_total, C0, row_offset, tol=1e-4, max_iter=300, check_every=1, group=None):
+    """KMeans(init=C0, n_init=1).fit over row-sharded, un-centred points: global mean / tolerance
+    by all-reduce of column sums, then ShardedLloyd.  C0 (un-centred) identical on every rank."""
+    from . import kernels as K
+    rank, ws = world()
+    d = X_local.shape[1]
+    col_sum = K.col_sums(X_local)
+    if ws > 1:
+        dist.all_reduce(col_sum, group=group)
+    mean64 = col_sum / n_total
+    sqdev = K.col_sqdev(X_local, mean64)
+    if ws > 1:
+        dist.all_reduce(sqdev, group=group)
+    tol_abs = float((sqdev / n_total).mean().item()) * tol if tol != 0 else 0.0
+    mean32 = mean64.to(torch.float32)
+    Xc = X_local.clone()
+    K.sub_rowvec_(Xc, mean32)
+    C0c = C0.clone().contiguous()
+    K.sub_rowvec_(C0c, mean32)
+    sl = ShardedLloyd(Xc, C0c, row_offset=row_offset, group=group)
+    labels, inertia, centers, n_iter = sl.run(max_iter=max_iter, tol_abs=tol_abs, check_every=check_every)
+    return dict(labels=labels, centers=centers + mean32, inertia=inertia, n_iter=n_iter, tol_abs=tol_abs)
