@@ -127,10 +127,13 @@ int mtp_lloyd_accumulate_f32(const float *X, int64_t n, int d, const int32_t *la
  * _kmeans.py:715-734).  C_new, staged, c2, shift[k] are written, red is zeroed, flags updated.
  * If a cluster is empty and relocation_done == 0 nothing is written except
  * flags = {RELOCATE, n_iter, n_empty}; the caller then runs mtp_far_points_f32 +
- * mtp_apply_relocation_f32 and calls this again with relocation_done = 1. */
+ * mtp_apply_relocation_f32 and calls this again with relocation_done = 1.
+ * red_backup (NULL or mtp_red_len doubles): on that pause red is MOVED there (red is zeroed),
+ * so that all-reduces a multi-GPU driver has already enqueued behind the pause add zeros
+ * instead of re-summing the reduced buffer; the driver copies it back before relocating. */
 int mtp_lloyd_mstep_f32(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
                         int relocation_done, float *staged, float *c2, float *shift, int32_t *flags,
-                        void *stream);
+                        double *red_backup, void *stream);
 
 /* Empty-cluster relocation, sklearn cluster/_k_means_common.pyx:167-211.
  * mtp_far_points_f32: the m points farthest from their assigned (old) centre, by

@@ -136,10 +136,10 @@ extern "C" int mtp_lloyd_estep_f32(const float *X, int64_t n, int d, const float
 
 extern "C" int mtp_lloyd_mstep_f32(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
                                    int relocation_done, float *staged, float *c2, float *shift, int32_t *flags,
-                                   void *stream) {
+                                   double *red_backup, void *stream) {
     MTP_REQUIRE(red && C_old && C_new && c2 && shift && flags && C_old != C_new, "mtp_lloyd_mstep: bad arguments");
     return mtp_launch_mstep(red, C_old, C_new, k, d, tol, max_iter, relocation_done, staged, c2, shift, flags,
-                            mtp_stream(stream));
+                            red_backup, mtp_stream(stream));
 }
 
 // ---- whole single-GPU run: sklearn _kmeans_single_lloyd (cluster/_kmeans.py:624-752) ----
@@ -174,7 +174,7 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
             rc = mtp_lloyd_estep_f32(X, n, d, cbuf[cur], w.staged, w.c2, k, labels_out, w.red, w.flags, stream);
             if (rc != MTP_OK) return rc;
             rc = mtp_launch_mstep(w.red, cbuf[cur], cbuf[cur ^ 1], k, d, tol_abs, max_iter, 0, w.staged, w.c2, w.shift,
-                                  w.flags, s);
+                                  w.flags, nullptr, s);
             if (rc != MTP_OK) return rc;
             cur ^= 1;
             ++enq_iters;
@@ -195,7 +195,7 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
             if (rc != MTP_OK) return rc;
             MTP_HIP(hipMemsetAsync(w.flags + MTP_FLAG_STATE, 0, 4, s));
             rc = mtp_launch_mstep(w.red, cbuf[old], cbuf[old ^ 1], k, d, tol_abs, max_iter, 1, w.staged, w.c2, w.shift,
-                                  w.flags, s);
+                                  w.flags, nullptr, s);
             if (rc != MTP_OK) return rc;
             cur = old ^ 1;
             enq_iters = done_iters + 1;

@@ -59,7 +59,8 @@ int mtp_launch_assign(const float *X, int64_t n, int d, const float *C, const fl
 int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,
                           double *counts, const int32_t *state, hipStream_t s);
 int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
-                     int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, hipStream_t s);
+                     int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, double *red_backup,
+                     hipStream_t s);
 int mtp_launch_inertia(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
                        float *per_point, hipStream_t s);
 

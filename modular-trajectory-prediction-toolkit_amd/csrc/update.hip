@@ -252,13 +252,21 @@ __global__ __launch_bounds__(64) void k_mstep_centers(double *red, const float *
 }
 
 __global__ __launch_bounds__(256) void k_mstep_flags(double *red, int k, int d, double tol, int max_iter,
-                                                     int relocation_done, const float *shift, int32_t *flags) {
+                                                     int relocation_done, const float *shift, int32_t *flags,
+                                                     double *red_backup) {
     __shared__ int scratch[4];
     __shared__ double dsum[4];
     if (flags[MTP_FLAG_STATE] != MTP_STATE_RUNNING) return;
     double *counts = red + (size_t)k * d;
     const int n_empty = block_count_empty(counts, k, scratch);
     if (n_empty > 0 && !relocation_done) {
+        if (red_backup != nullptr) {  // park the reduced buffer: later all-reduces then add zeros
+            const int64_t len = mtp_red_len(k, d);
+            for (int64_t e = threadIdx.x; e < len; e += blockDim.x) {
+                red_backup[e] = red[e];
+                red[e] = 0.0;
+            }
+        }
         if (threadIdx.x == 0) {
             flags[MTP_FLAG_STATE] = MTP_STATE_RELOCATE;
             flags[MTP_FLAG_N_EMPTY] = n_empty;
@@ -296,14 +304,15 @@ __global__ __launch_bounds__(256) void k_mstep_flags(double *red, int k, int d, 
 }
 
 int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
-                     int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, hipStream_t s) {
+                     int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, double *red_backup,
+                     hipStream_t s) {
     const bool mfma = mtp_mfma_dim(d);
     const int rows = mfma ? mtp_n_tiles(k) * 32 : k;
     hipLaunchKernelGGL(k_mstep_centers, dim3(rows), dim3(64), 2 * (size_t)d * sizeof(float), s, red, C_old, C_new, k, d,
                        relocation_done, mfma ? staged : nullptr, c2, shift, flags);
     MTP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mstep_flags, dim3(1), dim3(256), 0, s, red, k, d, tol, max_iter, relocation_done, shift,
-                       flags);
+                       flags, red_backup);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }

@@ -61,10 +61,10 @@ class DeviceOps:
         check(lib().mtp_lloyd_accumulate_f32(ptr(X), n, d, ptr(labels), k, ptr(red), ptr(flags), stream_ptr()),
               "mtp_lloyd_accumulate_f32")
 
-    def mstep(self, red, C_old, C_new, k, d, tol, max_iter, relocation_done, staged, c2, shift, flags):
+    def mstep(self, red, C_old, C_new, k, d, tol, max_iter, relocation_done, staged, c2, shift, flags, red_backup):
         check(lib().mtp_lloyd_mstep_f32(ptr(red), ptr(C_old), ptr(C_new), k, d, float(tol), int(max_iter),
                                         int(relocation_done), ptr(staged), ptr(c2), ptr(shift), ptr(flags),
-                                        stream_ptr()), "mtp_lloyd_mstep_f32")
+                                        ptr(red_backup), stream_ptr()), "mtp_lloyd_mstep_f32")
 
     def far_points(self, X, C_old, labels, m, idx_offset):
         n, d = X.shape
@@ -112,6 +112,7 @@ class ShardedLloyd:
         o = self.ops
         k, d = self.k, self.d
         self.red = o.zeros(k * d + k + 2, torch.float64)
+        self.red_backup = o.zeros(k * d + k + 2, torch.float64)  # where a paused M-step parks red
         self.flags = o.zeros(FLAG_WORDS, torch.int32)
         n_staged = int(lib().mtp_staged_centers_floats(k, d)) if ops is None else 0
         self.staged = o.zeros(max(n_staged, 4), torch.float32)
@@ -135,7 +136,7 @@ class ShardedLloyd:
 
     def mstep(self, tol, max_iter, relocation_done=0):
         self.ops.mstep(self.red, self.cbuf[self.cur], self.cbuf[self.cur ^ 1], self.k, self.d, tol, max_iter,
-                       relocation_done, self.staged, self.c2, self.shift, self.flags)
+                       relocation_done, self.staged, self.c2, self.shift, self.flags, self.red_backup)
 
     def step(self, tol, max_iter):
         self.assign()
@@ -165,6 +166,7 @@ class ShardedLloyd:
         """Global top-m farthest points -> apply to the (replicated) reduced buffer."""
         o = self.ops
         m = min(int(m), MAX_RELOC)
+        self.red.copy_(self.red_backup)  # the paused M-step parked the reduced buffer there
         val, idx, lab, rows = o.far_points(self.X, self.cbuf[old], self.labels, m, self.row_offset)
         if self.world > 1:
             gv = [torch.empty_like(val) for _ in range(self.world)]

@@ -1,0 +1,187 @@
+"""Multi-process (gloo, CPU) tests of the sharded Lloyd driver pccs_accel.dist.ShardedLloyd.
+
+The driver's logic -- shard bounds, the per-iteration all-reduce of the packed double buffer,
+replicated M-step, chunked flag checks, the all-gather based empty-cluster relocation, the
+final E-step and the inertia reduction -- is exercised with world_size 1, 2 and 3 over gloo.
+The HIP kernels are replaced by ``NumpyOps``, a CPU model of the step-level C-ABI built on the
+oracle (this is test code; the product's DeviceOps is what runs on a GPU).  Every world size
+must reproduce the oracle's single-process ``kmeans_single_lloyd``.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import datagen
+import kmeans_oracle as O
+from conftest import PKG_DIR, ROOT
+
+
+class NumpyOps:
+    """CPU model of include/mtp_accel.h's step-level entry points (same state machine)."""
+
+    def zeros(self, n, dtype):
+        return torch.zeros(n, dtype=dtype)
+
+    def begin(self, C, k, d, staged, c2, red, flags):
+        c2.copy_(torch.from_numpy(O.row_sqnorm(C.numpy())))
+        red.zero_()
+        flags.zero_()
+
+    def assign(self, X, C, staged, c2, k, labels, red, flags):
+        if int(flags[0]) != 0:
+            return
+        d = X.shape[1]
+        new = O.assign(X.numpy(), C.numpy(), c2.numpy()) if X.shape[0] else np.zeros(0, np.int32)
+        red[k * d + k] += float((new != labels.numpy()).sum())
+        labels.copy_(torch.from_numpy(new))
+
+    def accumulate(self, X, k, labels, red, flags):
+        if int(flags[0]) != 0 or X.shape[0] == 0:
+            return
+        d = X.shape[1]
+        s, w = O.accumulate_f64(X.numpy(), labels.numpy(), k)
+        red[:k * d] += torch.from_numpy(s.ravel())
+        red[k * d:k * d + k] += torch.from_numpy(w)
+
+    def mstep(self, red, C_old, C_new, k, d, tol, max_iter, relocation_done, staged, c2, shift, flags, red_backup):
+        if int(flags[0]) != 0:
+            return
+        counts = red[k * d:k * d + k].numpy()
+        n_empty = int((counts == 0).sum())
+        if n_empty > 0 and not relocation_done:
+            red_backup.copy_(red)
+            red.zero_()
+            flags[0] = 3
+            flags[2] = n_empty
+            return
+        sums = red[:k * d].numpy().reshape(k, d)
+        new = np.empty((k, d), dtype=np.float32)
+        heavy = int(np.argmax(counts))
+        for j in range(k):
+            src = j if counts[j] > 0 else heavy
+            alpha = np.float32(1.0) if (counts[j] == 0 and src > j) else np.float32(1.0) / np.float32(counts[src])
+            new[j] = sums[src].astype(np.float32) * alpha
+        sh = np.empty(k, dtype=np.float32)
+        old = np.ascontiguousarray(C_old.numpy())
+        O.lib().orc_center_shift(O._ptr(old), O._ptr(new), k, d, O._ptr(sh))
+        tot = float((sh * sh).astype(np.float64).sum())
+        n_changed = float(red[k * d + k])
+        C_new.copy_(torch.from_numpy(new))
+        c2.copy_(torch.from_numpy(O.row_sqnorm(new)))
+        shift.copy_(torch.from_numpy(sh))
+        red.zero_()
+        it = int(flags[1]) + 1
+        flags[1] = it
+        flags[2] = 0
+        flags[0] = 1 if n_changed == 0 else (2 if tot <= tol else (4 if it >= max_iter else 0))
+
+    def far_points(self, X, C_old, labels, m, idx_offset):
+        n, d = X.shape
+        val = torch.full((m,), -1.0, dtype=torch.float32)
+        idx = torch.full((m,), -1, dtype=torch.int64)
+        lab = torch.full((m,), -1, dtype=torch.int32)
+        rows = torch.zeros((m, d), dtype=torch.float32)
+        if n:
+            _, pp = O.inertia(X.numpy(), C_old.numpy(), labels.numpy(), return_per_point=True)
+            order = np.lexsort((np.arange(n), -pp))[:m]
+            for q, i in enumerate(order):
+                val[q], idx[q], lab[q] = float(pp[i]), int(i) + idx_offset, int(labels[i])
+                rows[q] = X[i]
+        return val, idx, lab, rows
+
+    def apply_relocation(self, red, k, d, m, val, lab, rows):
+        if not float(val[0]) > 0:
+            return
+        counts = red[k * d:k * d + k]
+        empties = [j for j in range(k) if float(counts[j]) == 0.0]
+        for i in range(min(len(empties), m)):
+            new_id, old_id = empties[i], int(lab[i])
+            if old_id < 0:
+                break
+            x = rows[i].to(torch.float64)
+            red[old_id * d:(old_id + 1) * d] -= x
+            red[new_id * d:(new_id + 1) * d] = x
+            counts[new_id] = 1.0
+            counts[old_id] -= 1.0
+
+    def final_assign(self, X, C, staged, c2, k, labels):
+        if X.shape[0]:
+            labels.copy_(torch.from_numpy(O.assign(X.numpy(), C.numpy(), c2.numpy())))
+
+    def inertia(self, X, C, labels):
+        v = O.inertia(X.numpy(), C.numpy(), labels.numpy()) if X.shape[0] else 0.0
+        return torch.tensor([v], dtype=torch.float64)
+
+
+def _case(which):
+    if which == "plain":
+        X = datagen.make_encodings(14, 1500, 16, 6, 1500, 900)
+        Xc = X - X.mean(axis=0)
+        C0 = Xc[datagen.make_init_indices(5, 1500, 24)].copy()
+    else:  # an unreachable centre -> empty cluster -> relocation through the all-gather path
+        X = datagen.make_encodings(15, 900, 8, 5, 2000, 300)
+        Xc = X - X.mean(axis=0)
+        C0 = Xc[datagen.make_init_indices(6, 900, 9)].copy()
+        C0[2] = 40.0
+        C0[7] = -35.0
+    return Xc, C0, float(O.tolerance(X))
+
+
+def _worker(rank, world, port, which, check_every, out_dir):
+    sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pccs_accel import dist as pdist
+    Xc, C0, tol = _case(which)
+    lo, hi = pdist.shard_bounds(Xc.shape[0], rank, world)
+    sl = pdist.ShardedLloyd(torch.from_numpy(Xc[lo:hi].copy()), torch.from_numpy(C0.copy()), row_offset=lo,
+                            ops=NumpyOps())
+    labels, inertia, centers, n_iter = sl.run(max_iter=300, tol_abs=tol, check_every=check_every)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), labels=labels.numpy(), centers=centers.numpy(), inertia=inertia,
+             n_iter=n_iter, lo=lo, hi=hi)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("which", ["plain", "relocate"])
+@pytest.mark.parametrize("world,check_every", [(1, 1), (2, 1), (2, 5), (3, 2)])
+def test_sharded_lloyd_matches_oracle(which, world, check_every, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), which, check_every, str(tmp_path)), nprocs=world, join=True)
+    Xc, C0, tol = _case(which)
+    ol, oi, oc, on = O.kmeans_single_lloyd(Xc, C0, 300, tol)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    labels = np.concatenate([p["labels"] for p in parts])
+    assert [int(p["lo"]) for p in parts] == sorted(int(p["lo"]) for p in parts) and int(parts[-1]["hi"]) == Xc.shape[0]
+    for p in parts:  # replicated state is identical on every rank
+        assert int(p["n_iter"]) == on
+        assert np.array_equal(p["centers"], parts[0]["centers"])
+        assert float(p["inertia"]) == float(parts[0]["inertia"])
+    assert np.array_equal(labels, ol)
+    assert np.allclose(parts[0]["centers"], oc, rtol=1e-5, atol=1e-6)
+    assert np.isclose(float(parts[0]["inertia"]), oi, rtol=1e-6)
+
+
+def test_shard_bounds_cover_everything():
+    sys.path.insert(0, PKG_DIR)
+    from pccs_accel.dist import shard_bounds
+    for n in (0, 1, 7, 10_000_000, 73_568):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [e - s for s, e in b]
+            assert max(sizes) - min(sizes) <= 1
