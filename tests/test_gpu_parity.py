@@ -334,3 +334,70 @@ def test_best_of_k_empty_and_bad_args(gpu_device):
         K.best_of_k(torch.zeros((2, 5, 12, 2), device=gpu_device), torch.zeros((2, 11, 2), device=gpu_device))
     with pytest.raises(ValueError):
         K.best_of_k(torch.zeros((2, 5, 12, 2), device=gpu_device), torch.zeros((2, 12, 2), device=gpu_device), mode=3)
+
+
+# ------------------------------------------------------------------------------------------
+# k-means++ seeding and the reference's call sites end to end
+# ------------------------------------------------------------------------------------------
+def test_kmeans_plusplus_replays_sklearn_draws(gpu_device):
+    """Device k-means++ with sklearn's RandomState stream picks sklearn's centre indices."""
+    from pccs_accel import seeding
+    g = load_golden("g9_kmeanspp")
+    X = datagen.make_encodings(int(g["seed"]), int(g["n"]), int(g["d"]), int(g["k_true"]))
+    Xc = X - X.mean(axis=0)
+    centers, ind = seeding.kmeans_plusplus(dev(Xc, gpu_device), int(g["K"]), np.random.RandomState(int(g["rs_seed"])))
+    assert np.array_equal(ind.cpu().numpy(), g["indices"])
+    assert np.array_equal(centers.cpu().numpy(), Xc[g["indices"]])
+
+
+def _same_partition(a, b):
+    """Label vectors equal up to a permutation of the cluster ids."""
+    pairs = set(zip(a.tolist(), b.tolist()))
+    return len(pairs) == len(set(a.tolist())) == len(set(b.tolist()))
+
+
+def test_cluster_data_seeded_dropin(gpu_device):
+    """np.random.seed(0); cluster_data(X, 20): k-means++ and 20 restarts on the GPU against the
+    reference's own output (golden G2).  dtypes and the size histogram are part of the contract."""
+    from pccs_accel.utils.utility import cluster_data
+    g = load_golden("g2_seeded_cluster_data")
+    X = datagen.make_encodings(int(g["seed"]), int(g["n"]), int(g["d"]), int(g["k_true"]))
+    np.random.seed(int(g["np_seed"]))
+    labels, sizes = cluster_data(X.copy(), int(g["K"]))
+    assert labels.dtype == np.int32 and sizes.dtype == np.int64 and sizes.sum() == len(X)
+    assert np.array_equal(np.bincount(labels, minlength=int(g["K"])), sizes)
+    assert np.array_equal(labels, g["labels"])
+    assert np.array_equal(sizes, g["sizes"])
+
+
+def test_cluster_data_xoe_pm_dropin(gpu_device):
+    """XOE variant: data[:, :obs_feat_size] *= pm before clustering (golden G8)."""
+    import argparse
+    from pccs_accel.utils.utility import cluster_data
+    g = load_golden("g8_xoe_pm")
+    X = datagen.make_encodings(int(g["seed"]), int(g["n"]), int(g["d"]), int(g["k_true"]))
+    np.random.seed(int(g["np_seed"]))
+    args = argparse.Namespace(pm=float(g["pm"]), obs_feat_size=int(g["obs_feat_size"]))
+    labels, sizes = cluster_data(X.copy(), n_cluster=int(g["K"]), save_dir=None, args=args)
+    assert np.array_equal(labels, g["labels"])
+    assert np.array_equal(sizes, g["sizes"])
+
+
+def test_get_memory_data_writes_reference_files(tmp_path, gpu_device):
+    """get_memory_data: cache miss -> memory.npy / cluster_result.npy / size_array.npy with the
+    reference's dtypes; second call hits the cache and returns the same arrays."""
+    import argparse
+    from pccs_accel.utils.utility import get_memory_data
+    X = datagen.make_encodings(61, 1200, 96, 10)
+    ds = argparse.Namespace(obs_enc=dev(X[:, :48].copy(), gpu_device), pred_enc=dev(X[:, 48:].copy(), gpu_device))
+    args = argparse.Namespace(n_cluster=10, no_time_check=True)
+    np.random.seed(1)
+    mem, labels, sizes = get_memory_data(ds, str(tmp_path), args)
+    assert mem.dtype == np.float32 and mem.shape == (1200, 96) and np.array_equal(mem, X)
+    for f, dt in (("memory.npy", np.float32), ("cluster_result.npy", np.int32), ("size_array.npy", np.int64)):
+        assert np.load(tmp_path / f).dtype == dt
+    mem2, labels2, sizes2 = get_memory_data(None, str(tmp_path), args)   # op 6: dataset is None, cache must hit
+    assert np.array_equal(labels, labels2) and np.array_equal(sizes, sizes2) and np.array_equal(mem, mem2)
+    np.random.seed(1)
+    ol, osz = O.cluster_data(X.copy(), 10)
+    assert _same_partition(labels, ol) and np.array_equal(np.sort(sizes), np.sort(osz))
