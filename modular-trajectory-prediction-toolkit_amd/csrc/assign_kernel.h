@@ -1,0 +1,183 @@
+// The fp32-MFMA E-step kernel (included by assign.hip and by tools/assign_tune.hip).
+#pragma once
+#include "mtp_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 16-byte LDS-DMA: LDS destination = wave-uniform byte address (M0) + lane*16, the global source
+// is per lane.  Written as inline asm on purpose: hipcc treats the builtin as a pending LDS
+// write and puts s_waitcnt vmcnt(0) in front of the next ds_read, which would serialise the
+// prefetch of stage t+1 with the MFMAs of stage t.  The asm form is invisible to its vmcnt
+// bookkeeping; the kernel waits for its own DMA (dma_wait) before the barrier that publishes a
+// stage.  M0 is saved/restored inside the statement (it is compiler-reserved).
+__device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_byte_addr_uniform)
+        : "memory");
+}
+// keeps a value live without cost (ablation builds); the asm only exists in the device pass
+__device__ __forceinline__ void keep_alive(const f32x16 &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#else
+    (void)v;
+#endif
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Template parameters: D feature size, PT 32-point tiles per wave, CTW 32-centroid tiles per LDS
+// stage, WPB waves per workgroup, WPS waves per SIMD the register budget is sized for (launch bound), EPI = false drops
+// the bias/argmin epilogue (tuning ablation only; the product always instantiates EPI = true).
+template <int D, int PT, int CTW, int WPB, int WPS, bool EPI>
+__global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__restrict__ X, int64_t n,
+                                                        const float *__restrict__ staged, int n_tiles,
+                                                        int32_t *__restrict__ labels, double *n_changed,
+                                                        const int32_t *state) {
+    constexpr int R = D / 4;                 // 16-byte slots per centroid row
+    constexpr int TILE_F = 32 * (D + 4) + 32;  // floats per 32-centroid tile image (rows padded by one slot)
+    constexpr int STAGE_F = CTW * TILE_F;
+    constexpr int STAGE_SLOTS = STAGE_F / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * STAGE_F floats
+
+    if (state != nullptr && *state != MTP_STATE_RUNNING) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t pbase = ((int64_t)blockIdx.x * WPB + wave) * (32 * PT);
+
+    // ---- B operands: this wave's points, k = 2s + h for step s, kept in registers ----
+    float xr[PT][D / 2];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int64_t row = pbase + pt * 32 + j;
+        if (row >= n) row = n - 1;  // tail rows are computed and discarded
+        const float4 *xp = reinterpret_cast<const float4 *>(X + row * D);
+#pragma unroll
+        for (int q = 0; q < D / 4; ++q) {
+            const float4 v = xp[q];
+            xr[pt][2 * q] = h ? v.y : v.x;
+            xr[pt][2 * q + 1] = h ? v.w : v.z;
+            // half of every 16-byte load is dropped: bound the loads in flight so the
+            // prologue does not spill
+            if (q % 8 == 7) asm volatile("" ::: "memory");
+        }
+    }
+
+    float best[PT];
+    int breg[PT], btile[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        best[pt] = __builtin_inff();
+        breg[pt] = 0;
+        btile[pt] = 0;
+    }
+
+    const int n_stages = n_tiles / CTW;
+    const int wave_slot0 = wave * 64;
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    auto stage = [&](int t) {
+        const float *g = staged + (size_t)t * STAGE_F;
+        const unsigned l = smem_base + (unsigned)((t & 1) * STAGE_F * 4);
+        for (int s0 = wave_slot0; s0 < STAGE_SLOTS; s0 += 64 * WPB) {
+            if (s0 + lane < STAGE_SLOTS)
+                glds16(g + (size_t)(s0 + lane) * 4, __builtin_amdgcn_readfirstlane(l + (unsigned)s0 * 16));
+        }
+    };
+
+    stage(0);
+    for (int t = 0; t < n_stages; ++t) {
+        dma_wait();       // this wave's share of stage t has landed ...
+        __syncthreads();  // ... and so has everyone else's; all waves are done with the other buffer
+        if (t + 1 < n_stages) stage(t + 1);
+        const float *sb = smem + (t & 1) * STAGE_F;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            const float *tb = sb + ct * TILE_F;
+            const float4 *arow = reinterpret_cast<const float4 *>(tb) + j * (R + 1) + h;
+            f32x16 acc[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pt][r] = 0.f;
+            // A operands one u-step ahead of the MFMAs that use them; the compiler fence keeps it
+            // from hoisting all D/8 ds_read_b128 to the top (64 VGPRs) and spilling.
+            float4 a = arow[0];
+#pragma unroll
+            for (int u = 0; u < D / 8; ++u) {
+                float4 an = a;
+                if (u + 1 < D / 8) an = arow[2 * (u + 1)];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xr[pt][4 * u + 0], acc[pt], 0, 0, 0);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xr[pt][4 * u + 1], acc[pt], 0, 0, 0);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xr[pt][4 * u + 2], acc[pt], 0, 0, 0);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xr[pt][4 * u + 3], acc[pt], 0, 0, 0);
+                asm volatile("" ::: "memory");
+                a = an;
+            }
+            if constexpr (!EPI) {  // ablation: keep the accumulators alive, skip the epilogue
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) keep_alive(acc[pt]);
+                continue;
+            }
+            // epilogue: d = c2 - 2*dot (one rounding), strict '<' in ascending centroid order.
+            // The running argmin is kept as (tile, accumulator register): the register number
+            // is an inline constant of the select, the tile is updated once per tile.
+            float before[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) before[pt] = best[pt];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 c2v = *reinterpret_cast<const float4 *>(tb + 32 * (D + 4) + 8 * g + 4 * h);
+                const float c2a[4] = {c2v.x, c2v.y, c2v.z, c2v.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        const float dist = fmaf(-2.0f, acc[pt][4 * g + r], c2a[r]);
+                        const bool lt = dist < best[pt];
+                        best[pt] = lt ? dist : best[pt];
+                        breg[pt] = lt ? (4 * g + r) : breg[pt];
+                    }
+                }
+            }
+            const int tile = t * CTW + ct;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) btile[pt] = (best[pt] < before[pt]) ? tile : btile[pt];
+        }
+    }
+
+    // merge the two lane halves (rows 4h.. interleave): lexicographic (dist, index) minimum
+    int changed = 0;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        // accumulator register r of lane half h is centroid row (r&3) + 8(r>>2) + 4h of its tile
+        const int mine = btile[pt] * 32 + (breg[pt] & 3) + 8 * (breg[pt] >> 2) + 4 * h;
+        const float ob = __shfl_xor(best[pt], 32);
+        const int oi = __shfl_xor(mine, 32);
+        const bool take = (ob < best[pt]) || (ob == best[pt] && oi < mine);
+        const int lab = take ? oi : mine;
+        const int64_t row = pbase + pt * 32 + j;
+        if (h == 0 && row < n) {
+            const int old = labels[row];
+            labels[row] = lab;
+            changed += (old != lab);
+        }
+    }
+    if (n_changed != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) changed += __shfl_xor(changed, o);
+        if (lane == 0 && changed != 0) atomicAdd(n_changed, (double)changed);
+    }
+}
+

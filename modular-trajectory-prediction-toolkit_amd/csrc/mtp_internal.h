@@ -32,19 +32,19 @@ void mtp_set_error(const char *fmt, ...);
 // ------------------------------------------------------------------------------------------
 // Staged centroid image (what the MFMA E-step streams through LDS).
 //
-// Centroids are grouped in tiles of 32 rows.  One tile image = 32*R 16-byte slots + 8 slots of
-// ||c||^2, R = d/4.  Row i's slot p = 2u + h holds the four floats C[i][8u + h + 2e], e=0..3:
+// Centroids are grouped in tiles of 32 rows.  One tile image = 32*(R+1) 16-byte slots + 8 slots
+// of ||c||^2, R = d/4.  Row i's slot p = 2u + h holds the four floats C[i][8u + h + 2e], e=0..3:
 // the A operands of lane (i, h) for MFMA k-steps 4u..4u+3 (v_mfma_f32_32x32x2_f32 takes
 // k = 2s + h from lane half h at step s, so the dot product runs in natural k order).
-// Slot p of row i is stored at i*R + (p ^ swz(i)); the XOR makes the 16-lane groups of a
-// ds_read_b128 hit 16 distinct 16-byte bank slots for R % 16 == 0 and R % 16 == 8.
+// Rows are R+1 slots apart (one pad slot): the 16-lane groups of a ds_read_b128 then hit
+// (i*(R+1) + p) mod 16 = (c*i + p) mod 16 with c odd for R = 16, 24, 32 -> 16 distinct 16-byte
+// bank slots, and every read address is one per-lane base + a compile-time offset.
 // ------------------------------------------------------------------------------------------
-constexpr int MTP_CTW = 2;  // 32-centroid tiles per LDS stage
+constexpr int MTP_TILE_PAD = 4;  // the image holds a multiple of 4 tiles (any CTW in {1, 2, 4} divides it)
 
 __host__ __device__ inline bool mtp_mfma_dim(int d) { return d == 64 || d == 96 || d == 128; }
-__host__ __device__ inline int mtp_tile_floats(int d) { return 32 * d + 32; }
-__host__ __device__ inline int mtp_n_tiles(int k) { return ((k + 32 * MTP_CTW - 1) / (32 * MTP_CTW)) * MTP_CTW; }
-__host__ __device__ inline int mtp_swz(int i, int R) { return (R % 16 == 0) ? (i & 15) : ((i >> 1) & 7); }
+__host__ __device__ inline int mtp_tile_floats(int d) { return 32 * (d + 4) + 32; }
+__host__ __device__ inline int mtp_n_tiles(int k) { return ((k + 32 * MTP_TILE_PAD - 1) / (32 * MTP_TILE_PAD)) * MTP_TILE_PAD; }
 
 // The sklearn Lloyd "red" buffer layout: sums[k*d], counts[k], n_changed, spare
 __host__ __device__ inline int64_t mtp_red_len(int k, int d) { return (int64_t)k * d + k + 2; }
@@ -99,7 +99,10 @@ __device__ inline void mtp_write_staged_row(float *staged, int j, int d, const f
         const int u = p >> 1, h = p & 1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) v = make_float4(row[8 * u + h], row[8 * u + h + 2], row[8 * u + h + 4], row[8 * u + h + 6]);
-        reinterpret_cast<float4 *>(tb)[i * R + (p ^ mtp_swz(i, R))] = v;
+        reinterpret_cast<float4 *>(tb)[i * (R + 1) + p] = v;
     }
-    if (tid == 0) tb[32 * d + i] = valid ? c2v : __builtin_inff();
+    if (tid == 0) {
+        reinterpret_cast<float4 *>(tb)[i * (R + 1) + R] = make_float4(0.f, 0.f, 0.f, 0.f);  // pad slot
+        tb[32 * (d + 4) + i] = valid ? c2v : __builtin_inff();
+    }
 }

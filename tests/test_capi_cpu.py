@@ -51,11 +51,11 @@ def test_geometry_helpers_without_gpu():
     L = _lib.lib()
     assert L.mtp_version() >= 100
     # 200 centroids -> 8 tiles of 32 (padded to whole 2-tile LDS stages), 32*96+32 floats each
-    assert L.mtp_staged_centers_floats(200, 96) == 8 * (32 * 96 + 32)
-    assert L.mtp_staged_centers_floats(1024, 128) == 32 * (32 * 128 + 32)
+    assert L.mtp_staged_centers_floats(200, 96) == 8 * (32 * (96 + 4) + 32)
+    assert L.mtp_staged_centers_floats(1024, 128) == 32 * (32 * (128 + 4) + 32)
     assert L.mtp_staged_centers_floats(5, 2) == 0  # generic kernel: no staged image
     assert L.mtp_lloyd_workspace_bytes(1024, 128) > 1024 * 128 * 8
-    assert L.mtp_assign_workspace_bytes(200, 96) >= 8 * (32 * 96 + 32) * 4 + 200 * 4
+    assert L.mtp_assign_workspace_bytes(200, 96) >= 8 * (32 * (96 + 4) + 32) * 4 + 200 * 4
 
 
 def test_argument_errors_are_reported_not_faulted():

@@ -1,0 +1,111 @@
+// Development micro-benchmark (not part of the product): times variants of the MFMA E-step kernel
+// on one GPU, interleaved in one process, and checks that every variant with the epilogue
+// produces identical labels.  Build: make -C tools   Run (GPU box): tools/assign_tune [N] [K]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "assign_kernel.h"
+
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e = (x);                                                        \
+        if (e != hipSuccess) {                                                     \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            exit(1);                                                               \
+        }                                                                          \
+    } while (0)
+
+__global__ void k_fill(float *p, size_t n, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = ((int)(x >> 8) - (1 << 23)) * (1.0f / (1 << 23));
+    }
+}
+
+struct Variant {
+    const char *name;
+    void (*launch)(const float *, int64_t, const float *, int, int32_t *, hipStream_t);
+    bool epi;
+};
+
+template <int D, int PT, int CTW, int WPB, int WPS, bool EPI>
+void launch_v(const float *X, int64_t n, const float *staged, int k, int32_t *labels, hipStream_t s) {
+    const size_t lds = 2 * (size_t)CTW * mtp_tile_floats(D) * sizeof(float);
+    static bool set = false;
+    if (!set) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign_mfma<D, PT, CTW, WPB, WPS, EPI>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        set = true;
+    }
+    const int64_t ppb = WPB * 32 * PT;
+    hipLaunchKernelGGL((k_assign_mfma<D, PT, CTW, WPB, WPS, EPI>), dim3((unsigned)((n + ppb - 1) / ppb)), dim3(64 * WPB), lds, s, X,
+                       n, staged, mtp_n_tiles(k), labels, nullptr, nullptr);
+    CK(hipGetLastError());
+}
+
+int main(int argc, char **argv) {
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 10000000;
+    const int k = argc > 2 ? atoi(argv[2]) : 1024;
+    constexpr int D = 128;
+    float *X, *C, *staged, *c2;
+    int32_t *labels, *ref;
+    CK(hipMalloc(&X, n * D * 4));
+    CK(hipMalloc(&C, (size_t)k * D * 4));
+    CK(hipMalloc(&staged, (size_t)mtp_n_tiles(k) * mtp_tile_floats(D) * 4));
+    CK(hipMalloc(&c2, k * 4));
+    CK(hipMalloc(&labels, n * 4));
+    CK(hipMalloc(&ref, n * 4));
+    k_fill<<<4096, 256>>>(X, (size_t)n * D, 1);
+    k_fill<<<256, 256>>>(C, (size_t)k * D, 7);
+    if (mtp_launch_stage_centers(C, k, D, staged, c2, nullptr, 0) != 0) { printf("stage failed\n"); return 1; }
+    CK(hipDeviceSynchronize());
+
+    std::vector<Variant> vs = {
+        {"PT2 CTW2 WPB4 WPS2 (product)", launch_v<D, 2, 2, 4, 2, true>, true},
+        {"PT2 CTW2 WPB4 WPS2 no-epi", launch_v<D, 2, 2, 4, 2, false>, false},
+        {"PT2 CTW2 WPB8 WPS2", launch_v<D, 2, 2, 8, 2, true>, true},
+        {"PT1 CTW2 WPB8 WPS4", launch_v<D, 1, 2, 8, 4, true>, true},
+        {"PT1 CTW2 WPB8 WPS4 no-epi", launch_v<D, 1, 2, 8, 4, false>, false},
+        {"PT1 CTW1 WPB4 WPS4", launch_v<D, 1, 1, 4, 4, true>, true},
+        {"PT1 CTW2 WPB16 WPS4", launch_v<D, 1, 2, 16, 4, true>, true},
+        {"PT1 CTW2 WPB8 WPS3", launch_v<D, 1, 2, 8, 3, true>, true},
+    };
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int rounds = 4;
+    std::vector<std::vector<float>> ms(vs.size());
+    vs[0].launch(X, n, staged, k, ref, 0);
+    CK(hipDeviceSynchronize());
+    std::vector<int32_t> href(n), hl(n);
+    CK(hipMemcpy(href.data(), ref, n * 4, hipMemcpyDeviceToHost));
+    for (int r = 0; r < rounds; ++r) {
+        for (size_t v = 0; v < vs.size(); ++v) {
+            CK(hipMemset(labels, 0xff, n * 4));
+            CK(hipEventRecord(e0, 0));
+            vs[v].launch(X, n, staged, k, labels, 0);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float t;
+            CK(hipEventElapsedTime(&t, e0, e1));
+            ms[v].push_back(t);
+            if (r == 0 && vs[v].epi) {
+                CK(hipMemcpy(hl.data(), labels, n * 4, hipMemcpyDeviceToHost));
+                size_t bad = 0;
+                for (int64_t i = 0; i < n; ++i) bad += hl[i] != href[i];
+                if (bad) printf("  !! %s: %zu label mismatches vs product variant\n", vs[v].name, bad);
+            }
+        }
+    }
+    const double flop = 2.0 * n * k * D;
+    for (size_t v = 0; v < vs.size(); ++v) {
+        float mn = 1e30f, sum = 0;
+        for (int r = 1; r < rounds; ++r) { mn = ms[v][r] < mn ? ms[v][r] : mn; sum += ms[v][r]; }
+        const float avg = sum / (rounds - 1);
+        printf("%-30s min %7.3f ms  avg %7.3f ms  %6.1f TFLOP/s (%4.1f%% of 157.3)\n", vs[v].name, mn, avg,
+               flop / (mn * 1e-3) / 1e12, flop / (mn * 1e-3) / 1e12 / 157.3 * 100);
+    }
+    return 0;
+}
