@@ -1,0 +1,138 @@
+// The segmented centroid-sum kernel (included by update.hip and by tools/accumulate_tune.hip).
+//
+// grid = (row chunks, cluster ranges).  A workgroup owns clusters [k0, k0+kr) in LDS and scans the
+// labels of its row chunk; rows whose label is in range are fetched (16 B per lane, LPR lanes
+// per row, 64/LPR rows per wave instruction) and added in LDS; the partials are flushed with
+// global double atomics.  LDS layout per cluster row: element 4c+e stored at e*(d/4) + c, so
+// consecutive lanes hit consecutive accumulators for a fixed e.
+#pragma once
+#include "mtp_internal.h"
+
+// ACC = double (product) or float (tuning only): the LDS accumulator type.  G = groups of
+// 64/LPR rows whose loads are issued together before their LDS adds.  DO_ADD = false skips the
+// LDS adds (tuning ablation: load-only time).
+template <int LPR, int G, typename ACC, bool DO_ADD>
+__global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X, int64_t n, int d,
+                                                     const int32_t *__restrict__ labels, int k, int kr,
+                                                     int64_t rows_per_chunk, double *sums, double *counts,
+                                                     const int32_t *state) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];  // kr*d ACC, then kr ints
+    ACC *acc = reinterpret_cast<ACC *>(acc_raw);
+    if (state != nullptr && *state != MTP_STATE_RUNNING) return;
+    const int k0 = blockIdx.y * kr;
+    const int kn = min(kr, k - k0);
+    int *cnt = reinterpret_cast<int *>(acc + (size_t)kr * d);
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    for (int e = tid; e < kn * d; e += nthreads) acc[e] = (ACC)0;
+    for (int e = tid; e < kn; e += nthreads) cnt[e] = 0;
+    __syncthreads();
+
+    constexpr int RPW = 64 / LPR;  // rows per wave instruction
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int sub = lane / LPR, c0 = lane % LPR;
+    const int dq = d / 4;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_chunk;
+    const int64_t r_end = min(n, r_begin + rows_per_chunk);
+    const int64_t stride = (int64_t)nwaves * 64;
+
+    // Software pipeline over "trips" (up to G groups of RPW matching rows): the row loads of
+    // trip i+1 are issued before the LDS adds of trip i, so a wave always has loads in flight.
+    int64_t base = r_begin + (int64_t)wave * 64;
+    int lab_next = -1;
+    if (base + lane < r_end) lab_next = labels[base + lane];
+    int rel = -1;
+    unsigned long long m = 0;
+    bool first = true;
+    float4 vc[G];
+    int rc[G];
+    const float *pc[G];
+    bool have_cur = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        rc[g] = -1;
+        pc[g] = nullptr;
+        vc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (;;) {
+        // advance to the next batch of 64 labels that has a row for this cluster range
+        while (m == 0 && base < r_end) {
+            if (!first) base += stride;
+            first = false;
+            if (base >= r_end) break;
+            rel = lab_next - k0;
+            lab_next = -1;  // the batch after this one travels while this one's rows are fetched
+            if (base + stride + lane < r_end) lab_next = labels[base + stride + lane];
+            const bool hit = (rel >= 0) && (rel < kn);
+            m = __ballot(hit);
+            if (hit) atomicAdd(&cnt[rel], 1);
+        }
+        const bool have_nxt = (m != 0);
+        float4 vn[G];
+        int rn[G];
+        const float *pn[G];
+        if (have_nxt) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                int b = -1;
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) {
+                    const int bit = m ? (int)__builtin_ctzll(m) : -1;
+                    if (m) m &= m - 1;
+                    if (q == sub) b = bit;
+                }
+                const int r = __shfl(rel, b < 0 ? 0 : b);
+                rn[g] = (b >= 0 && c0 < dq) ? r : -1;
+                pn[g] = X + (base + (b < 0 ? 0 : b)) * d;
+                vn[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rn[g] >= 0) vn[g] = reinterpret_cast<const float4 *>(pn[g])[c0];
+            }
+        }
+        if (have_cur) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (rc[g] >= 0) {
+                    if constexpr (DO_ADD) {
+                        ACC *a = acc + (size_t)rc[g] * d + c0;
+                        atomicAdd(a, (ACC)vc[g].x);
+                        atomicAdd(a + dq, (ACC)vc[g].y);
+                        atomicAdd(a + 2 * dq, (ACC)vc[g].z);
+                        atomicAdd(a + 3 * dq, (ACC)vc[g].w);
+                        // rows wider than LPR*4 floats: remaining 16-byte chunks
+                        for (int c = c0 + LPR; c < dq; c += LPR) {
+                            const float4 w = reinterpret_cast<const float4 *>(pc[g])[c];
+                            atomicAdd(a + (c - c0), (ACC)w.x);
+                            atomicAdd(a + (c - c0) + dq, (ACC)w.y);
+                            atomicAdd(a + (c - c0) + 2 * dq, (ACC)w.z);
+                            atomicAdd(a + (c - c0) + 3 * dq, (ACC)w.w);
+                        }
+                    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("" ::"v"(vc[g].x), "v"(vc[g].y), "v"(vc[g].z), "v"(vc[g].w));
+#endif
+                    }
+                }
+            }
+        }
+        if (!have_nxt) break;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            vc[g] = vn[g];
+            rc[g] = rn[g];
+            pc[g] = pn[g];
+        }
+        have_cur = true;
+    }
+    __syncthreads();
+    // flush: LDS element (row, e*dq + c) is column 4c+e
+    for (int idx = tid; idx < kn * d; idx += nthreads) {
+        const double v = (double)acc[idx];
+        if (v != 0.0) {
+            const int row = idx / d, off = idx % d;
+            const int e = off / dq, c = off % dq;
+            atomicAdd(&sums[(size_t)(k0 + row) * d + 4 * c + e], v);
+        }
+    }
+    for (int idx = tid; idx < kn; idx += nthreads)
+        if (cnt[idx] != 0) atomicAdd(&counts[k0 + idx], (double)cnt[idx]);
+}
+

@@ -12,106 +12,7 @@
 // Sums are accumulated in double (LDS ds_add_f64, then global_atomic_add_f64): the order of the
 // additions then changes the result only at the 1e-16 level, so centroids do not depend on the
 // workgroup schedule or on how many GPUs share the points.
-#include "mtp_internal.h"
-
-// ------------------------------------------------------------------------------------------
-// k_accumulate.  grid = (n_chunks, n_ranges).  A workgroup owns clusters [k0, k0+kr) in LDS as
-// doubles and scans the labels of its row chunk; rows whose label is in range are fetched
-// (16 B per lane, LPR lanes per row, 64/LPR rows per wave instruction) and added in LDS.
-// LDS layout per cluster row: element 4c+e stored at e*(d/4) + c -> consecutive lanes hit
-// consecutive doubles for a fixed e.
-// ------------------------------------------------------------------------------------------
-template <int LPR>
-__global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X, int64_t n, int d,
-                                                     const int32_t *__restrict__ labels, int k, int kr,
-                                                     int64_t rows_per_chunk, double *sums, double *counts,
-                                                     const int32_t *state) {
-    extern __shared__ __attribute__((aligned(16))) double acc[];  // kr*d doubles, then kr ints
-    if (state != nullptr && *state != MTP_STATE_RUNNING) return;
-    const int k0 = blockIdx.y * kr;
-    const int kn = min(kr, k - k0);
-    int *cnt = reinterpret_cast<int *>(acc + (size_t)kr * d);
-    const int tid = threadIdx.x, nthreads = blockDim.x;
-    for (int e = tid; e < kn * d; e += nthreads) acc[e] = 0.0;
-    for (int e = tid; e < kn; e += nthreads) cnt[e] = 0;
-    __syncthreads();
-
-    constexpr int RPW = 64 / LPR;  // rows per wave instruction
-    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
-    const int sub = lane / LPR, c0 = lane % LPR;
-    const int dq = d / 4;
-    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_chunk;
-    const int64_t r_end = min(n, r_begin + rows_per_chunk);
-
-    for (int64_t base = r_begin + (int64_t)wave * 64; base < r_end; base += (int64_t)nwaves * 64) {
-        const int64_t myrow = base + lane;
-        int lab = -1;
-        if (myrow < r_end) lab = labels[myrow];
-        const int rel = lab - k0;
-        const bool hit = (rel >= 0) && (rel < kn);
-        unsigned long long m = __ballot(hit);
-        if (hit) atomicAdd(&cnt[rel], 1);
-        while (m) {
-            // up to 4 groups of RPW matching rows per trip: issue all row loads, then the LDS adds
-            int bsel[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int b = -1;
-#pragma unroll
-                for (int q = 0; q < RPW; ++q) {
-                    const int bit = m ? (int)__builtin_ctzll(m) : -1;
-                    if (m) m &= m - 1;
-                    if (q == sub) b = bit;
-                }
-                bsel[g] = b;
-            }
-            float4 v[4];
-            int relsel[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                relsel[g] = __shfl(rel, bsel[g] < 0 ? 0 : bsel[g]);
-                v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (bsel[g] >= 0 && c0 < dq) v[g] = reinterpret_cast<const float4 *>(X + (base + bsel[g]) * d)[c0];
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (bsel[g] >= 0 && c0 < dq) {
-                    double *a = acc + (size_t)relsel[g] * d + c0;
-                    atomicAdd(a, (double)v[g].x);
-                    atomicAdd(a + dq, (double)v[g].y);
-                    atomicAdd(a + 2 * dq, (double)v[g].z);
-                    atomicAdd(a + 3 * dq, (double)v[g].w);
-                }
-            }
-            // rows wider than LPR*4 floats: remaining 16-byte chunks
-            for (int c = c0 + LPR; c < dq; c += LPR) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (bsel[g] >= 0) {
-                        const float4 w = reinterpret_cast<const float4 *>(X + (base + bsel[g]) * d)[c];
-                        double *a = acc + (size_t)relsel[g] * d + c;
-                        atomicAdd(a, (double)w.x);
-                        atomicAdd(a + dq, (double)w.y);
-                        atomicAdd(a + 2 * dq, (double)w.z);
-                        atomicAdd(a + 3 * dq, (double)w.w);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // flush: LDS element (row, e*dq + c) is column 4c+e
-    for (int idx = tid; idx < kn * d; idx += nthreads) {
-        const double v = acc[idx];
-        if (v != 0.0) {
-            const int row = idx / d, off = idx % d;
-            const int e = off / dq, c = off % dq;
-            atomicAdd(&sums[(size_t)(k0 + row) * d + 4 * c + e], v);
-        }
-    }
-    for (int idx = tid; idx < kn; idx += nthreads)
-        if (cnt[idx] != 0) atomicAdd(&counts[k0 + idx], (double)cnt[idx]);
-}
+#include "accumulate_kernel.h"
 
 // scalar fallback for d % 4 != 0 (known-answer tests): plain global double atomics
 __global__ __launch_bounds__(256) void k_accumulate_scalar(const float *__restrict__ X, int64_t n, int d,
@@ -158,11 +59,11 @@ int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *label
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            MTP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate<LPR>),                        \
+            MTP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate<LPR, 4, double, true>),                        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES + 1024));   \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL(k_accumulate<LPR>, grid, dim3(1024), lds, s, X, n, d, labels, k, kr, rows_per_chunk,    \
+        hipLaunchKernelGGL((k_accumulate<LPR, 4, double, true>), grid, dim3(1024), lds, s, X, n, d, labels, k, kr, rows_per_chunk,    \
                            sums, counts, state);                                                                   \
     } while (0)
     if (dq <= 8)
