@@ -158,6 +158,16 @@ int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int m
                   int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, void *ws,
                   size_t ws_bytes, void *stream);
 
+/* k-means++ seeding, sklearn cluster/_kmeans.py:174-272 with unit sample weights, for one
+ * restart.  The caller draws the random numbers from the same NumPy RandomState in sklearn's
+ * order -- center_id = rs.choice(n, p=w/w.sum()), then u = rs.uniform(size=(k-1, l)) with
+ * l = 2 + int(ln k) -- and passes u as a DEVICE array.  Only enqueues (2 launches per centre);
+ * indices_out[k] (int64) and centers_out[k, d] = X[indices_out] are device arrays.
+ * ws: mtp_kpp_workspace_bytes(n, d, l) bytes. */
+int64_t mtp_kpp_workspace_bytes(int64_t n, int d, int l);
+int mtp_kmeans_plusplus_f32(const float *X, int64_t n, int d, int k, int l, int64_t center_id, const double *u,
+                            int64_t *indices_out, float *centers_out, void *ws, size_t ws_bytes, void *stream);
+
 /* Best-of-K ADE/FDE.  pred [n, kstride, t, 2], gt [n, t, 2]; the first k (<= kstride)
  * candidates of every agent are scored:
  *   ADE_c = (sum_t ||gt_t - pred_c,t||) / ade_div,  FDE_c = ||gt_T - pred_c,T||

@@ -1,0 +1,349 @@
+// k-means++ seeding on gfx950, replaying scikit-learn's algorithm and random stream.
+//
+// Replaces sklearn cluster/_kmeans.py:174-272 (_kmeans_plusplus, unit weights) as called once per
+// restart by KMeans.fit (PCCSNet/utils/utility.py:120-121 hard-codes n_init=20): at reference
+// scale (N=73 568, K=200) seeding is >50 % of the CPU wall time.
+//
+// The host draws the random numbers (NumPy RandomState, same order as sklearn) and uploads them
+// once; everything else is enqueued without a host sync: per new centre two launches,
+//   k_kpp_select  (1 workgroup)  pick the best of the previous candidates (argmin of potentials),
+//                                then locate the L new candidates: rand_l = u_l * pot,
+//                                searchsorted(cumsum(closest), rand_l) via block sums + one
+//                                in-block scan per candidate, clip to N-1; gather their rows
+//   k_kpp_dist    (N/1024 WGs)   d = fp32(max(0, (-2 x.y + |x|^2) + |y|^2)) in double for the L
+//                                candidates (sklearn metrics/pairwise.py:391-442,582-653: float32
+//                                input is upcast, stored back as float32, clamped), min with the
+//                                closest-so-far, per-block double sums (the potentials)
+// np.cumsum / the BLAS sums are replaced by double tree sums: differences ~1e-16 relative.
+#include "mtp_internal.h"
+
+static constexpr int KPP_PB = 256;     // points per block of k_kpp_dist (one per thread)
+static constexpr int KPP_Q = KPP_PB / 64;  // points per lane in the in-block scan
+static constexpr int KPP_MAX_L = 16;   // local trials: 2 + int(ln K) <= 16 up to K ~ 1.2e6
+
+struct KppWs {
+    double *yy;        // [n]  |y|^2 of the upcast rows
+    float *rows;       // [2][L][n] closest-distance rows (ping-pong over steps)
+    double *bsum;      // [2][L][nblk] per-block sums of those rows
+    double *prefix;    // [nblk] scratch: inclusive prefix of the selected row's block sums
+    double *cand_x;    // [L][d] candidate rows in double
+    double *cand_xx;   // [L]
+    int64_t *cand;     // [L] candidate ids
+    int32_t *state;    // [0] = selected candidate of the current rows
+    float *pot;        // [1] current potential (float32 like sklearn's)
+    size_t bytes;
+};
+
+static inline size_t kpp_align(size_t v) { return (v + 255) / 256 * 256; }
+
+static KppWs kpp_carve(void *ws, int64_t n, int d, int l) {
+    KppWs w;
+    const int64_t nblk = (n + KPP_PB - 1) / KPP_PB;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *p = ws ? static_cast<char *>(ws) + off : nullptr;
+        off += kpp_align(bytes);
+        return p;
+    };
+    w.yy = static_cast<double *>(take((size_t)n * 8));
+    w.rows = static_cast<float *>(take((size_t)2 * l * n * 4));
+    w.bsum = static_cast<double *>(take((size_t)2 * l * nblk * 8));
+    w.prefix = static_cast<double *>(take((size_t)nblk * 8));
+    w.cand_x = static_cast<double *>(take((size_t)l * d * 8));
+    w.cand_xx = static_cast<double *>(take((size_t)l * 8));
+    w.cand = static_cast<int64_t *>(take((size_t)l * 8));
+    w.state = static_cast<int32_t *>(take(64));
+    w.pot = static_cast<float *>(take(64));
+    w.bytes = off;
+    return w;
+}
+
+extern "C" int64_t mtp_kpp_workspace_bytes(int64_t n, int d, int l) {
+    if (n <= 0 || d <= 0 || l <= 0 || l > KPP_MAX_L) return 0;
+    return (int64_t)kpp_carve(nullptr, n, d, l).bytes;
+}
+
+// |y|^2 per row in double
+__global__ __launch_bounds__(256) void k_kpp_rownorm(const float *__restrict__ X, int64_t n, int d, double *yy) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *x = X + i * d;
+    double s = 0.0;
+    for (int k = 0; k < d; ++k) s = fma((double)x[k], (double)x[k], s);
+    yy[i] = s;
+}
+
+// Distances from n_cand (<= LT) candidate rows (double, in cand_x) to every point; min with the
+// previous closest row (or none when has_prev == 0); block sums.  KPP_PB/256 points per thread; every
+// point row is converted to double once and used for all candidates.
+template <int LT>
+__global__ __launch_bounds__(256) void k_kpp_dist(const float *__restrict__ X, int64_t n, int d, int n_cand,
+                                                  const double *__restrict__ cand_x,
+                                                  const double *__restrict__ cand_xx, const double *__restrict__ yy,
+                                                  const float *rows_prev /* [L][n] */, const int32_t *sel_prev,
+                                                  int has_prev, float *rows_out /* [L][n] */, double *bsum_out,
+                                                  int64_t nblk) {
+    extern __shared__ __attribute__((aligned(16))) double sx[];  // LT * d candidate rows (zero padded)
+    __shared__ double part[LT][4];
+    for (int e = threadIdx.x; e < LT * d; e += 256) sx[e] = e < n_cand * d ? cand_x[e] : 0.0;
+    __syncthreads();
+    const float *prev = has_prev ? rows_prev + (size_t)(*sel_prev) * n : nullptr;
+    double acc[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) acc[l] = 0.0;
+    const int64_t base = (int64_t)blockIdx.x * KPP_PB;
+    for (int r = 0; r < KPP_PB / 256; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const float *y = X + i * d;
+        double dot[LT];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) dot[l] = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double yv = (double)y[k];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) dot[l] = fma(sx[l * d + k], yv, dot[l]);
+        }
+        const double yyi = yy[i];
+        const float old = prev ? prev[i] : __builtin_inff();
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            if (l < n_cand) {
+                double dd = -2.0 * dot[l];
+                dd += cand_xx[l];
+                dd += yyi;
+                float f = (float)dd;
+                f = f > 0.f ? f : 0.f;  // np.maximum(d, 0)
+                f = f < old ? f : old;  // np.minimum(closest_dist_sq, distance_to_candidates)
+                rows_out[(size_t)l * n + i] = f;
+                acc[l] += (double)f;
+            }
+        }
+    }
+    // block sums (fixed tree: wave shuffles, then the 4 wave partials in order)
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        double v = acc[l];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) part[l][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < n_cand) {
+        const int l = threadIdx.x;
+        bsum_out[(size_t)l * nblk + blockIdx.x] = (part[l][0] + part[l][1]) + (part[l][2] + part[l][3]);
+    }
+}
+
+static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const KppWs &w, const float *rows_prev,
+                           int has_prev, float *rows_out, double *bsum_out, int64_t nblk, hipStream_t s) {
+    const dim3 grid((unsigned)nblk), block(256);
+    if (n_cand == 1)
+        hipLaunchKernelGGL(k_kpp_dist<1>, grid, block, (size_t)1 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy,
+                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk);
+    else if (n_cand <= 8)
+        hipLaunchKernelGGL(k_kpp_dist<8>, grid, block, (size_t)8 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy,
+                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk);
+    else
+        hipLaunchKernelGGL(k_kpp_dist<16>, grid, block, (size_t)16 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx,
+                           w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out, nblk);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+// One workgroup of 1024 threads.  (1) potentials of the n_prev candidate rows = sums of their block
+// sums; best = first argmin (float32 compare like np.argmin on the float32 potentials); record the
+// chosen centre.  (2) if n_new > 0: draw positions for the next n_new candidates.
+__global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X, int64_t n, int d, int n_prev,
+                                                     int n_new, const double *__restrict__ u /* [n_new] */,
+                                                     const float *rows_cur, const double *bsum_cur, int64_t nblk,
+                                                     double *prefix, int64_t *cand, double *cand_x, double *cand_xx,
+                                                     int32_t *state, float *pot_out, int64_t *index_out) {
+    __shared__ double red[16];
+    __shared__ float pots[KPP_MAX_L];
+    __shared__ int s_sel;
+    __shared__ double s_rand[KPP_MAX_L];
+    __shared__ int s_blk[KPP_MAX_L];
+    __shared__ double s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // (1) potentials
+    for (int l = 0; l < n_prev; ++l) {
+        double v = 0.0;
+        for (int64_t b = tid; b < nblk; b += 1024) v += bsum_cur[(size_t)l * nblk + b];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 16; ++w) t += red[w];
+            pots[l] = (float)t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int best = 0;
+        for (int l = 1; l < n_prev; ++l)
+            if (pots[l] < pots[best]) best = l;
+        s_sel = best;
+        state[0] = best;
+        pot_out[0] = pots[best];
+        index_out[0] = cand[best];
+        for (int l = 0; l < n_new; ++l) {
+            s_rand[l] = u[l] * (double)pots[best];  // random_state.uniform(size=L) * current_pot
+            s_blk[l] = 0;
+        }
+        s_carry = 0.0;
+    }
+    __syncthreads();
+    if (n_new == 0) return;
+    const int sel = s_sel;
+    const double *bs = bsum_cur + (size_t)sel * nblk;
+    const float *row = rows_cur + (size_t)sel * n;
+
+    // (2a) inclusive prefix of the block sums, chunks of 1024 with a running carry; for every
+    // candidate count the blocks whose prefix is still below its draw (= index of its block)
+    for (int64_t b0 = 0; b0 < nblk; b0 += 1024) {
+        const int64_t b = b0 + tid;
+        double v = b < nblk ? bs[b] : 0.0;
+        // wave inclusive scan
+        for (int o = 1; o < 64; o <<= 1) {
+            const double t = __shfl_up(v, o);
+            if (lane >= o) v += t;
+        }
+        if (lane == 63) red[wave] = v;
+        __syncthreads();
+        double woff = 0.0;
+        for (int w = 0; w < wave; ++w) woff += red[w];
+        const double carry = s_carry;
+        v += woff + carry;
+        if (b < nblk) {
+            prefix[b] = v;
+            for (int l = 0; l < n_new; ++l)
+                if (v < s_rand[l]) atomicAdd(&s_blk[l], 1);
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = v;
+        __syncthreads();
+    }
+    // (2b) one wave per candidate: scan its block's points (KPP_Q per lane) for the first cumulative
+    // sum >= draw (np.searchsorted side='left'); past the end -> clip to n-1
+    for (int l = wave; l < n_new; l += 16) {
+        const int blk = s_blk[l];
+        int64_t id = n - 1;
+        if (blk < nblk) {
+            const double start = blk > 0 ? prefix[blk - 1] : 0.0;
+            const int64_t p0 = (int64_t)blk * KPP_PB + lane * KPP_Q;
+            double loc[KPP_Q];
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < KPP_Q; ++q) {
+                const int64_t i = p0 + q;
+                s += (i < n) ? (double)row[i] : 0.0;
+                loc[q] = s;
+            }
+            double incl = s;
+            for (int o = 1; o < 64; o <<= 1) {
+                const double t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const double excl = start + (incl - s);
+            int first = KPP_Q;
+#pragma unroll
+            for (int q = KPP_Q - 1; q >= 0; --q)
+                if (excl + loc[q] >= s_rand[l]) first = q;
+            const unsigned long long mask = __ballot(first < KPP_Q);
+            if (mask) {
+                const int wl = (int)__builtin_ctzll(mask);
+                const int fq = __shfl(first, wl);
+                const int64_t cid = (int64_t)blk * KPP_PB + wl * KPP_Q + fq;
+                id = cid < n ? cid : n - 1;
+            } else {
+                // rounding put the draw past this block's end: first point of the next block
+                const int64_t cid = (int64_t)(blk + 1) * KPP_PB;
+                id = cid < n ? cid : n - 1;
+            }
+        }
+        if (lane == 0) cand[l] = id;
+        // gather the candidate row in double and its squared norm
+        const float *x = X + id * d;
+        double xx = 0.0;
+        for (int k = lane; k < d; k += 64) {
+            const double v = (double)x[k];
+            cand_x[(size_t)l * d + k] = v;
+            xx += v * v;
+        }
+        for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
+        if (lane == 0) cand_xx[l] = xx;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_kpp_first(const float *__restrict__ X, int d, int64_t center_id, int64_t *cand,
+                                                  double *cand_x, double *cand_xx) {
+    const int lane = threadIdx.x;
+    const float *x = X + center_id * d;
+    double xx = 0.0;
+    for (int k = lane; k < d; k += 64) {
+        const double v = (double)x[k];
+        cand_x[k] = v;
+        xx += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
+    if (lane == 0) {
+        cand_xx[0] = xx;
+        cand[0] = center_id;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X, int d, const int64_t *idx, int k,
+                                                     float *out) {
+    const int j = blockIdx.x;
+    const float *x = X + idx[j] * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)j * d + c] = x[c];
+}
+
+extern "C" int mtp_kmeans_plusplus_f32(const float *X, int64_t n, int d, int k, int l, int64_t center_id,
+                                       const double *u, int64_t *indices_out, float *centers_out, void *ws,
+                                       size_t ws_bytes, void *stream) {
+    MTP_REQUIRE(X && indices_out && centers_out && ws, "mtp_kmeans_plusplus: null pointer");
+    MTP_REQUIRE(n >= 1 && d >= 1 && k >= 1 && k <= n, "mtp_kmeans_plusplus: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
+    MTP_REQUIRE(l >= 1 && l <= KPP_MAX_L, "mtp_kmeans_plusplus: n_local_trials must be in [1, %d] (got %d)", KPP_MAX_L, l);
+    MTP_REQUIRE(center_id >= 0 && center_id < n, "mtp_kmeans_plusplus: first centre index out of range");
+    MTP_REQUIRE(k == 1 || u != nullptr, "mtp_kmeans_plusplus: uniform draws missing");
+    MTP_REQUIRE((size_t)(l <= 8 ? 8 : 16) * d * 8 <= 60 * 1024, "mtp_kmeans_plusplus: d too large for the candidate tile");
+    KppWs w = kpp_carve(ws, n, d, l);
+    if (ws_bytes < w.bytes) {
+        mtp_set_error("mtp_kmeans_plusplus: workspace of %zu bytes, need %zu", ws_bytes, w.bytes);
+        return MTP_E_WORKSPACE;
+    }
+    hipStream_t s = mtp_stream(stream);
+    const int64_t nblk = (n + KPP_PB - 1) / KPP_PB;
+    MTP_REQUIRE(nblk <= 0x7fffffff, "mtp_kmeans_plusplus: n too large");
+    hipLaunchKernelGGL(k_kpp_rownorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, n, d, w.yy);
+    MTP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_kpp_first, dim3(1), dim3(64), 0, s, X, d, center_id, w.cand, w.cand_x, w.cand_xx);
+    MTP_LAUNCH_CHECK();
+    // closest distances to the first centre: one "candidate", no previous row
+    int rc = launch_kpp_dist(X, n, d, 1, w, nullptr, 0, w.rows, w.bsum, nblk, s);
+    if (rc != MTP_OK) return rc;
+    int cur = 0, n_prev = 1;
+    for (int c = 1; c <= k; ++c) {
+        // select among the previous candidates -> centre c-1; draw the candidates for centre c
+        const int n_new = c < k ? l : 0;
+        float *rows_cur = w.rows + (size_t)cur * l * n;
+        double *bsum_cur = w.bsum + (size_t)cur * l * nblk;
+        hipLaunchKernelGGL(k_kpp_select, dim3(1), dim3(1024), 0, s, X, n, d, n_prev, n_new,
+                           c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
+                           w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1));
+        MTP_LAUNCH_CHECK();
+        if (c == k) break;
+        float *rows_nxt = w.rows + (size_t)(cur ^ 1) * l * n;
+        double *bsum_nxt = w.bsum + (size_t)(cur ^ 1) * l * nblk;
+        rc = launch_kpp_dist(X, n, d, l, w, rows_cur, 1, rows_nxt, bsum_nxt, nblk, s);
+        if (rc != MTP_OK) return rc;
+        cur ^= 1;
+        n_prev = l;
+    }
+    hipLaunchKernelGGL(k_gather_rows, dim3(k), dim3(128), 0, s, X, d, indices_out, k, centers_out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
