@@ -83,7 +83,7 @@ def assign(X, C, labels=None, n_changed=None):
         raise ValueError(f"C has {C.shape[1]} features, X has {d}")
     if labels is None:
         labels = torch.full((n,), -1, dtype=torch.int32, device=X.device)
-    _req(labels, "labels", torch.int32, 1)
+    _req(labels, "labels", torch.int32, 1, align=4)
     assert labels.numel() == n
     if n_changed is not None:
         _req(n_changed, "n_changed", torch.float64, 1)
@@ -98,7 +98,7 @@ def assign(X, C, labels=None, n_changed=None):
 def centroid_sums(X, labels, k, sums=None, counts=None):
     """sums [k, d] float64 += member rows, counts [k] float64 += member counts."""
     _req(X, "X", torch.float32, 2)
-    _req(labels, "labels", torch.int32, 1)
+    _req(labels, "labels", torch.int32, 1, align=4)
     n, d = X.shape
     assert labels.numel() == n
     if sums is None:
@@ -129,7 +129,7 @@ def cluster_means(sums, counts):
 def inertia(X, C, labels, per_point=False):
     _req(X, "X", torch.float32, 2)
     _req(C, "C", torch.float32, 2)
-    _req(labels, "labels", torch.int32, 1)
+    _req(labels, "labels", torch.int32, 1, align=4)
     n, d = X.shape
     assert C.shape[1] == d and labels.numel() == n
     out = torch.zeros(1, dtype=torch.float64, device=X.device)

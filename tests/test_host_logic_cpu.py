@@ -1,0 +1,94 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no kernel calls):
+cache / staleness logic of get_memory_data (PCCSNet/utils/utility.py:64-85, checkings.py:4-22),
+argument validation, shard bookkeeping."""
+import argparse
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+
+def _args(**kw):
+    base = dict(n_cluster=5, no_time_check=False)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def _touch(path, t):
+    with open(path, "ab"):
+        pass
+    os.utime(path, (t, t))
+
+
+def test_get_memory_data_cache_hit_needs_no_gpu(tmp_path):
+    """With valid cached artefacts nothing is recomputed (dataset may be None, as in op 6)."""
+    from pccs_accel.utils.utility import get_memory_data
+    mem = np.arange(40, dtype=np.float32).reshape(10, 4)
+    labels = np.array([0, 1, 2, 3, 4, 0, 1, 2, 3, 4], dtype=np.int32)
+    sizes = np.full(5, 2, dtype=np.int64)
+    for name in ("Obs_Encoder.pth", "Pred_Encoder.pth"):
+        (tmp_path / name).write_bytes(b"x")
+    time.sleep(0.02)
+    np.save(tmp_path / "memory.npy", mem)
+    time.sleep(0.02)
+    np.save(tmp_path / "cluster_result.npy", labels)
+    np.save(tmp_path / "size_array.npy", sizes)
+    m, l, s = get_memory_data(None, str(tmp_path), _args())
+    assert np.array_equal(m, mem) and np.array_equal(l, labels) and np.array_equal(s, sizes)
+    assert l.dtype == np.int32 and s.dtype == np.int64
+
+
+def test_consistency_checks_follow_reference_rules(tmp_path):
+    from pccs_accel.utils.checkings import check_cluster_consistency, check_memory_consistency
+    for name in ("Obs_Encoder.pth", "Pred_Encoder.pth"):
+        (tmp_path / name).write_bytes(b"x")
+    time.sleep(0.02)
+    (tmp_path / "memory.npy").write_bytes(b"x")
+    time.sleep(0.02)
+    (tmp_path / "cluster_result.npy").write_bytes(b"x")
+    a = _args()
+    assert check_memory_consistency(str(tmp_path), a)
+    assert check_cluster_consistency(str(tmp_path), np.zeros(5), a)
+    assert not check_cluster_consistency(str(tmp_path), np.zeros(4), a)       # wrong n_cluster
+    time.sleep(0.02)
+    (tmp_path / "Obs_Encoder.pth").write_bytes(b"y")                         # encoder retrained after memory
+    assert not check_memory_consistency(str(tmp_path), a)
+    assert check_memory_consistency(str(tmp_path), _args(no_time_check=True))
+    time.sleep(0.02)
+    (tmp_path / "memory.npy").write_bytes(b"y")                              # memory newer than clusters
+    assert not check_cluster_consistency(str(tmp_path), np.zeros(5), a)
+    assert check_cluster_consistency(str(tmp_path), np.zeros(4), _args(no_time_check=True))
+
+
+def test_stale_cache_triggers_reclustering_which_needs_the_gpu(tmp_path):
+    """A size_array of the wrong length invalidates the cache; the recompute path then reaches
+    the HIP kernels and must fail loudly here (no GPU), never fall back to a CPU path."""
+    from pccs_accel._lib import MtpError
+    from pccs_accel.utils.utility import get_memory_data
+    np.save(tmp_path / "memory.npy", np.zeros((10, 4), dtype=np.float32))
+    np.save(tmp_path / "cluster_result.npy", np.zeros(10, dtype=np.int32))
+    np.save(tmp_path / "size_array.npy", np.zeros(3, dtype=np.int64))
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the recompute path would succeed")
+    with pytest.raises((MtpError, RuntimeError, AssertionError)):
+        get_memory_data(None, str(tmp_path), _args(n_cluster=5, no_time_check=True))
+
+
+def test_kmeans_fit_rejects_bad_input_before_any_launch():
+    from pccs_accel.clustering import kmeans_fit
+    with pytest.raises(TypeError):
+        kmeans_fit(torch.zeros(10, 4), 2)                 # CPU tensor
+    with pytest.raises(TypeError):
+        kmeans_fit(np.zeros((10, 4), np.float32), 2)      # not a tensor
+
+
+def test_modules_mirror_reference_names():
+    import pccs_accel.utils.metrics as M
+    import pccs_accel.utils.utility as U
+    for name in ("get_memory_data", "cluster_data", "k_means_cluster", "get_modality"):
+        assert callable(getattr(U, name))
+    for name in ("displacement_error", "final_displacement_error"):
+        assert callable(getattr(M, name))
+    from pccs_accel.evaluation import best_of_k, evaluate  # noqa: F401
