@@ -67,13 +67,17 @@ def test_stale_cache_triggers_reclustering_which_needs_the_gpu(tmp_path):
     the HIP kernels and must fail loudly here (no GPU), never fall back to a CPU path."""
     from pccs_accel._lib import MtpError
     from pccs_accel.utils.utility import get_memory_data
+    for name in ("Obs_Encoder.pth", "Pred_Encoder.pth"):
+        (tmp_path / name).write_bytes(b"x")
+    time.sleep(0.02)
     np.save(tmp_path / "memory.npy", np.zeros((10, 4), dtype=np.float32))
+    time.sleep(0.02)
     np.save(tmp_path / "cluster_result.npy", np.zeros(10, dtype=np.int32))
     np.save(tmp_path / "size_array.npy", np.zeros(3, dtype=np.int64))
     if torch.cuda.is_available():
         pytest.skip("GPU present: the recompute path would succeed")
     with pytest.raises((MtpError, RuntimeError, AssertionError)):
-        get_memory_data(None, str(tmp_path), _args(n_cluster=5, no_time_check=True))
+        get_memory_data(None, str(tmp_path), _args(n_cluster=5, no_time_check=False))
 
 
 def test_kmeans_fit_rejects_bad_input_before_any_launch():
