@@ -30,12 +30,18 @@ __device__ __forceinline__ void keep_alive(const f32x16 &v) {
     (void)v;
 #endif
 }
+__device__ __forceinline__ void pin2(float &a, float &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(a), "+v"(b));
+#endif
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Template parameters: D feature size, PT 32-point tiles per wave, CTW 32-centroid tiles per LDS
+// Template parameters (LG: 16-byte point loads in flight in the prologue, must divide D/4; PRIO:
+// raised wave priority during the MFMA run of a tile): D feature size, PT 32-point tiles per wave, CTW 32-centroid tiles per LDS
 // stage, WPB waves per workgroup, WPS waves per SIMD the register budget is sized for (launch bound), EPI = false drops
 // the bias/argmin epilogue (tuning ablation only; the product always instantiates EPI = true).
-template <int D, int PT, int CTW, int WPB, int WPS, bool EPI>
+template <int D, int PT, int CTW, int WPB, int WPS, bool EPI, int LG = 8, bool PRIO = false>
 __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__restrict__ X, int64_t n,
                                                         const float *__restrict__ staged, int n_tiles,
                                                         int32_t *__restrict__ labels, double *n_changed,
@@ -60,14 +66,21 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
         int64_t row = pbase + pt * 32 + j;
         if (row >= n) row = n - 1;  // tail rows are computed and discarded
         const float4 *xp = reinterpret_cast<const float4 *>(X + row * D);
+        // groups of LG 16-byte loads in flight; half of every load is dropped by the select.
+        // pin2 keeps the selects next to their loads: sunk below the first branch they made the
+        // compiler hold all D raw values at once and spill.
 #pragma unroll
-        for (int q = 0; q < D / 4; ++q) {
-            const float4 v = xp[q];
-            xr[pt][2 * q] = h ? v.y : v.x;
-            xr[pt][2 * q + 1] = h ? v.w : v.z;
-            // half of every 16-byte load is dropped: bound the loads in flight so the
-            // prologue does not spill
-            if (q % 8 == 7) asm volatile("" ::: "memory");
+        for (int q0 = 0; q0 < D / 4; q0 += LG) {
+            float4 v[LG];
+#pragma unroll
+            for (int g = 0; g < LG; ++g) v[g] = xp[q0 + g];
+#pragma unroll
+            for (int g = 0; g < LG; ++g) {
+                const int q = q0 + g;
+                xr[pt][2 * q] = h ? v[g].y : v[g].x;
+                xr[pt][2 * q + 1] = h ? v[g].w : v[g].z;
+                pin2(xr[pt][2 * q], xr[pt][2 * q + 1]);
+            }
         }
     }
 
@@ -110,6 +123,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
             // A operands one u-step ahead of the MFMAs that use them; the compiler fence keeps it
             // from hoisting all D/8 ds_read_b128 to the top (64 VGPRs) and spilling.
             float4 a = arow[0];
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int u = 0; u < D / 8; ++u) {
                 float4 an = a;
@@ -125,6 +139,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
                 asm volatile("" ::: "memory");
                 a = an;
             }
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
             if constexpr (!EPI) {  // ablation: keep the accumulators alive, skip the epilogue
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) keep_alive(acc[pt]);

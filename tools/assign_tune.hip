@@ -30,17 +30,17 @@ struct Variant {
     bool epi;
 };
 
-template <int D, int PT, int CTW, int WPB, int WPS, bool EPI>
+template <int D, int PT, int CTW, int WPB, int WPS, bool EPI, int LG = 8, bool PRIO = false>
 void launch_v(const float *X, int64_t n, const float *staged, int k, int32_t *labels, hipStream_t s) {
     const size_t lds = 2 * (size_t)CTW * mtp_tile_floats(D) * sizeof(float);
     static bool set = false;
     if (!set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign_mfma<D, PT, CTW, WPB, WPS, EPI>),
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign_mfma<D, PT, CTW, WPB, WPS, EPI, LG, PRIO>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         set = true;
     }
     const int64_t ppb = WPB * 32 * PT;
-    hipLaunchKernelGGL((k_assign_mfma<D, PT, CTW, WPB, WPS, EPI>), dim3((unsigned)((n + ppb - 1) / ppb)), dim3(64 * WPB), lds, s, X,
+    hipLaunchKernelGGL((k_assign_mfma<D, PT, CTW, WPB, WPS, EPI, LG, PRIO>), dim3((unsigned)((n + ppb - 1) / ppb)), dim3(64 * WPB), lds, s, X,
                        n, staged, mtp_n_tiles(k), labels, nullptr, nullptr);
     CK(hipGetLastError());
 }
@@ -63,10 +63,14 @@ int main(int argc, char **argv) {
     CK(hipDeviceSynchronize());
 
     std::vector<Variant> vs = {
-        {"PT2 CTW2 WPB4 WPS2 (product)", launch_v<D, 2, 2, 4, 2, true>, true},
-        {"PT2 CTW2 WPB4 WPS2 no-epi", launch_v<D, 2, 2, 4, 2, false>, false},
-        {"PT2 CTW2 WPB8 WPS2", launch_v<D, 2, 2, 8, 2, true>, true},
-        {"PT1 CTW2 WPB8 WPS4", launch_v<D, 1, 2, 8, 4, true>, true},
+        {"PT1 CTW2 WPB8 WPS4 (product)", launch_v<D, 1, 2, 8, 4, true>, true},
+        {"PT1 CTW2 WPB8 WPS4 LG16", launch_v<D, 1, 2, 8, 4, true, 16>, true},
+        {"PT1 CTW2 WPB8 WPS4 LG4", launch_v<D, 1, 2, 8, 4, true, 4>, true},
+        {"PT1 CTW2 WPB8 WPS4 PRIO", launch_v<D, 1, 2, 8, 4, true, 8, true>, true},
+        {"PT1 CTW2 WPB8 WPS4 LG16 PRIO", launch_v<D, 1, 2, 8, 4, true, 16, true>, true},
+        {"PT2 CTW2 WPB4 WPS2", launch_v<D, 2, 2, 4, 2, true>, true},
+        {"PT1 CTW4 WPB16 WPS4", launch_v<D, 1, 4, 16, 4, true>, true},
+        {"PT1 CTW1 WPB8 WPS4", launch_v<D, 1, 1, 8, 4, true>, true},
         {"PT1 CTW2 WPB8 WPS4 no-epi", launch_v<D, 1, 2, 8, 4, false>, false},
         {"PT1 CTW1 WPB4 WPS4", launch_v<D, 1, 1, 4, 4, true>, true},
         {"PT1 CTW2 WPB16 WPS4", launch_v<D, 1, 2, 16, 4, true>, true},
