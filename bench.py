@@ -39,6 +39,20 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md, HBM3E peak (spec); ~6300 achievable
 
 
+def recorded_traffic(n, d, k, world, eval_cfg=None):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json, written by
+    tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this very
+    command).  Counters cannot be read from inside the process, so the JSON line carries the
+    recorded figure, and only when the workload is the one the passes were taken on."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return {}
+    if world != 1 or (t.get("n"), t.get("d"), t.get("k")) != (n, d, k):
+        return {}
+    return t.get("hbm_bytes_per_launch", {})
+
+
 def make_encodings(n, d, k_true, seed, device):
     """X = tanh(M[z] + 0.15*eps), M ~ N(0, 0.5^2) [k_true, d]; values in (-1, 1)."""
     g = torch.Generator(device=device)
@@ -118,6 +132,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=5_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo); not a valid scaling result")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,10 +145,15 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
             sys.exit(2)
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from pccs_accel import dist as pdist
     from pccs_accel import kernels as K
@@ -141,6 +163,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def allreduce(t, op=dist.ReduceOp.SUM):
+        """RCCL on the device buffer; under gloo (rehearsals) staged through the host."""
+        if args.backend == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
     n, d, k = args.n, args.d, args.k
     lo, hi = pdist.shard_bounds(n, rank, world)
     n_local = hi - lo
@@ -148,12 +179,14 @@ def main():
     # fixed init: K rows of rank 0's shard, the same on every rank
     perm = torch.randperm(min(n_local, 1 << 22), generator=torch.Generator().manual_seed(3))[:k].to(device)
     C0 = X[perm].contiguous()
-    if world > 1:
-        dist.broadcast(C0, src=0)
+    if world > 1:  # rank 0's rows everywhere (a sum with zeros: one code path for RCCL and gloo)
+        if rank != 0:
+            C0.zero_()
+        allreduce(C0)
     # centring as KMeans.fit does (global mean)
     col = K.col_sums(X)
     if world > 1:
-        dist.all_reduce(col)
+        allreduce(col)
     mean32 = (col / n).to(torch.float32)
     K.sub_rowvec_(X, mean32)
     K.sub_rowvec_(C0, mean32)
@@ -190,7 +223,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        allreduce(tmax, dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     flags = sl.read_flags()
@@ -205,22 +238,24 @@ def main():
     ms_step = dt / args.steps * 1e3
     evals_per_s = float(n) * k * d * args.steps / dt
 
+    traffic = recorded_traffic(n, d, k, world)
     # roofline of the dominant kernel, per launch, on this rank's shard
     flop = 2.0 * n_local * k * d
     achieved_tf = flop / (ms_assign * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": "k_assign_mfma", "achieved": achieved_tf, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved_tf / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved_tf / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic.get("k_assign_mfma"),
                 "ms_per_launch": ms_assign, "algorithmic_flop_per_launch": flop}
     acc_bytes = n_local * d * 4.0 + n_local * 4.0 + k * d * 8.0 + k * 8.0
     roofline_update = {"bound": "hbm", "kernel": "k_accumulate", "achieved": acc_bytes / (ms_accum * 1e-3) / 1e9,
                        "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": acc_bytes / (ms_accum * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                       "traffic": None, "ms_per_launch": ms_accum, "algorithmic_bytes_per_launch": acc_bytes}
+                       "traffic": traffic.get("k_accumulate"), "ms_per_launch": ms_accum, "algorithmic_bytes_per_launch": acc_bytes}
 
     out = {
         "metric": "k-means iters/sec (N×K×D distance evals/sec) + best-of-K ADE/FDE traj/sec",
         "value": evals_per_s, "unit": "distance-evals/s (N*K*D MACs of the cross term per second, whole job)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" + (" (REHEARSAL: all ranks on one device, not a scaling result)" if args.one_device else ""),
         "config": {"workload": f"k-means Lloyd iterations, synthetic encodings N={n} D={d} K={k}, fixed init, "
                                f"points sharded over {world} GPU(s)" + (", RCCL all-reduce of sums/counts" if world > 1 else ""),
                    "n": n, "d": d, "k": k, "parallelism": f"points/{world}"},
@@ -245,12 +280,12 @@ def main():
             r = K.best_of_k(pred, gt, mode=i % 3)
         e1.record()
         if world > 1:
-            dist.all_reduce(r["sums"])
+            allreduce(r["sums"])
         barrier()
         edt = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([edt], dtype=torch.float64, device=device)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            allreduce(tmax, dist.ReduceOp.MAX)
             edt = float(tmax.item())
         ms_eval = e0.elapsed_time(e1) / reps
         ebytes = (ehi - elo) * (args.eval_k * args.eval_t * 2 * 4.0 + args.eval_t * 2 * 4.0 + 16.0)
@@ -260,7 +295,8 @@ def main():
             "ms_per_pass": edt / reps * 1e3,
             "roofline": {"bound": "hbm", "kernel": "k_best_of_k", "achieved": ebytes / (ms_eval * 1e-3) / 1e9,
                          "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ebytes / (ms_eval * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                         "traffic": None, "ms_per_launch": ms_eval, "algorithmic_bytes_per_launch": ebytes}}
+                         "traffic": traffic.get("k_best_of_k") if (args.eval_n, args.eval_k, args.eval_t) == (1_000_000, 100, 12) else None,
+                         "ms_per_launch": ms_eval, "algorithmic_bytes_per_launch": ebytes}}
         del pred, gt
 
     # ---- CPU baseline on a bounded sample (rank 0, N = 1 only) ----

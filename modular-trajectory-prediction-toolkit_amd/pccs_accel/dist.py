@@ -38,6 +38,31 @@ def shard_bounds(n_total, rank, world_size):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def _host_staged(group):
+    """gloo cannot be trusted with HIP device tensors (its device path hangs on ROCm for buffers
+    beyond a few KB), so under gloo -- rehearsals of the multi-rank driver on one GPU, CPU tests --
+    device buffers are staged through the host.  RCCL ("nccl") takes the device buffer as is."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t, group=None):
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def all_gather_cat(t, world_size, group=None):
+    """cat of every rank's ``t`` (same shape on all ranks) along dim 0, on t's device."""
+    src = t.cpu() if (t.is_cuda and _host_staged(group)) else t
+    parts = [torch.empty_like(src) for _ in range(world_size)]
+    dist.all_gather(parts, src, group=group)
+    return torch.cat(parts).to(t.device)
+
+
 class DeviceOps:
     """The HIP kernels behind the step-level C-ABI (include/mtp_accel.h)."""
 
@@ -132,7 +157,7 @@ class ShardedLloyd:
 
     def reduce(self):
         if self.world > 1:
-            dist.all_reduce(self.red, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_sum(self.red, self.group)
 
     def mstep(self, tol, max_iter, relocation_done=0):
         self.ops.mstep(self.red, self.cbuf[self.cur], self.cbuf[self.cur ^ 1], self.k, self.d, tol, max_iter,
@@ -169,22 +194,17 @@ class ShardedLloyd:
         self.red.copy_(self.red_backup)  # the paused M-step parked the reduced buffer there
         val, idx, lab, rows = o.far_points(self.X, self.cbuf[old], self.labels, m, self.row_offset)
         if self.world > 1:
-            gv = [torch.empty_like(val) for _ in range(self.world)]
-            gi = [torch.empty_like(idx) for _ in range(self.world)]
-            gl = [torch.empty_like(lab) for _ in range(self.world)]
-            gr = [torch.empty_like(rows) for _ in range(self.world)]
-            dist.all_gather(gv, val, group=self.group)
-            dist.all_gather(gi, idx, group=self.group)
-            dist.all_gather(gl, lab, group=self.group)
-            dist.all_gather(gr, rows, group=self.group)
-            v = torch.cat(gv).cpu().numpy()
-            i = torch.cat(gi).cpu().numpy()
+            gv = all_gather_cat(val, self.world, self.group)
+            gi = all_gather_cat(idx, self.world, self.group)
+            gl = all_gather_cat(lab, self.world, self.group)
+            gr = all_gather_cat(rows, self.world, self.group)
+            v = gv.cpu().numpy()
+            i = gi.cpu().numpy()
             # descending distance, ties to the lowest global row index; ranks without rows offer -1
             order = np.lexsort((i, -v))
             order = np.array([q for q in order if i[q] >= 0][:m], dtype=np.int64)
             sel = torch.from_numpy(order).to(val.device)
-            val, lab, rows = torch.cat(gv)[sel].contiguous(), torch.cat(gl)[sel].contiguous(), \
-                torch.cat(gr)[sel].contiguous()
+            val, lab, rows = gv[sel].contiguous(), gl[sel].contiguous(), gr[sel].contiguous()
             if val.numel() < m:  # fewer points than empty clusters: pad with "no candidate"
                 pad = m - val.numel()
                 val = torch.cat([val, val.new_full((pad,), -1.0)])
@@ -224,7 +244,7 @@ class ShardedLloyd:
             self.ops.final_assign(self.X, centers, self.staged, self.c2, self.k, self.labels)
         inertia = self.ops.inertia(self.X, centers, self.labels)
         if self.world > 1:
-            dist.all_reduce(inertia, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_sum(inertia, self.group)
         return self.labels, float(inertia.item()), centers, n_iter
 
 
@@ -236,11 +256,11 @@ def kmeans_fit_sharded(X_local, n_total, C0, row_offset, tol=1e-4, max_iter=300,
     d = X_local.shape[1]
     col_sum = K.col_sums(X_local)
     if ws > 1:
-        dist.all_reduce(col_sum, group=group)
+        all_reduce_sum(col_sum, group)
     mean64 = col_sum / n_total
     sqdev = K.col_sqdev(X_local, mean64)
     if ws > 1:
-        dist.all_reduce(sqdev, group=group)
+        all_reduce_sum(sqdev, group)
     tol_abs = float((sqdev / n_total).mean().item()) * tol if tol != 0 else 0.0
     mean32 = mean64.to(torch.float32)
     Xc = X_local.clone()

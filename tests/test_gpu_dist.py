@@ -1,0 +1,79 @@
+"""Sharded Lloyd with the real HIP kernels, world_size 2 and 3 on ONE GPU (gloo moves the packed
+reduce buffer; on a multi-GPU node the same driver runs over RCCL, one process per GPU).  Each
+world size must reproduce the single-process device run (itself checked against the CPU oracle
+in test_gpu_parity.py): identical labels and n_iter, centres to 1e-6 -- the double-accumulated
+sums make the trajectory independent of how the points are split.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import datagen
+from conftest import PKG_DIR, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(which):
+    if which == "plain":
+        X = datagen.make_encodings(21, 30011, 96, 50, 1500, 900)   # ragged: not a multiple of anything
+        C0 = X[datagen.make_init_indices(7, 30011, 200)].copy()
+    else:  # unreachable centres -> empty clusters -> relocation through the all-gather path
+        X = datagen.make_encodings(22, 9001, 128, 12, 2000, 300)
+        C0 = X[datagen.make_init_indices(8, 9001, 40)].copy()
+        C0[3] = 40.0
+        C0[17] = -35.0
+        C0[31] = 25.0
+    return X, C0
+
+
+def _worker(rank, world, port, which, check_every, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(60, exit=True)  # a stuck rank names its line and ends the test
+    sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pccs_accel import dist as pdist
+    X, C0 = _case(which)
+    dev = torch.device("cuda:0")
+    lo, hi = pdist.shard_bounds(X.shape[0], rank, world)
+    fit = pdist.kmeans_fit_sharded(torch.from_numpy(X[lo:hi].copy()).to(dev), X.shape[0], torch.from_numpy(C0).to(dev),
+                                   row_offset=lo, check_every=check_every)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), labels=fit["labels"].cpu().numpy(),
+             centers=fit["centers"].cpu().numpy(), inertia=fit["inertia"], n_iter=fit["n_iter"], lo=lo, hi=hi)
+    dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("which", ["plain", "relocate"])
+@pytest.mark.parametrize("world,check_every", [(2, 1), (3, 4)])
+def test_sharded_device_lloyd_matches_single(which, world, check_every, tmp_path, gpu_device):
+    from pccs_accel import clustering
+    mp.spawn(_worker, args=(world, _free_port(), which, check_every, str(tmp_path)), nprocs=world, join=True)
+    X, C0 = _case(which)
+    single = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), C0.shape[0], init=torch.from_numpy(C0))
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    labels = np.concatenate([p["labels"] for p in parts])
+    for p in parts:
+        assert int(p["n_iter"]) == single["n_iter"]
+        assert np.array_equal(p["centers"], parts[0]["centers"])
+        assert float(p["inertia"]) == float(parts[0]["inertia"])
+    assert np.array_equal(labels, single["labels"].cpu().numpy())
+    assert np.allclose(parts[0]["centers"], single["centers"].cpu().numpy(), rtol=1e-6, atol=1e-7)
+    assert np.isclose(float(parts[0]["inertia"]), single["inertia"], rtol=1e-9)
