@@ -188,6 +188,58 @@ int mtp_best_of_k_f64(const double *pred, const double *gt, int64_t n, int k, in
 int mtp_ade_fde_f32(const float *pred, const float *gt, int64_t n, int k, int kstride, int t, float ade_div,
                     float *ade, float *fde, void *stream);
 
+/* ---- decode glue around the evaluation ---- */
+
+/* out[a, c, j, :] = M_a @ (sum_{i<=j} disp[a, c, i, :]) + last_obs[a]   (float32, [n, k, t, 2]).
+ * Replaces transform_trajectory (PCCSNet/utils/data_process.py:111-122: in-place prefix sum over
+ * time, float adds in time order -- with rot = last_obs = NULL the result is bit-identical) and
+ * the rotate-back + last-position add of gen_prediction (PCCSNet/train_steps.py:253-255:
+ * torch.bmm(mat.repeat(k,1,1), out.transpose(1,2)).transpose(1,2) + last_obs).
+ * rot [n, 2, 2] or NULL (identity), last_obs [n, 2] or NULL (zero); out may alias disp. */
+int mtp_decode_trajectories_f32(const float *disp, int64_t n, int k, int t, const float *rot, const float *last_obs,
+                                float *out, void *stream);
+
+/* mtp_best_of_k_f32 on the network's raw per-step displacements: the prefix sum of
+ * transform_trajectory runs inside the scoring pass (PCCSNet/train_steps.py:216-220 in one
+ * launch); the decoded trajectories are never written. */
+int mtp_best_of_k_disp_f32(const float *disp, const float *gt, int64_t n, int k, int kstride, int t, float ade_div,
+                           int mode, float *min_ade, float *min_fde, int32_t *idx, int32_t *idx2, double *sums,
+                           void *stream);
+
+/* ---- score-sorted NMS re-ranking of stored prediction sets (section 8, row f4) ---- */
+
+/* Per agent: sort the first max_samples candidates by binned verification score (descending;
+ * score // bin_size as NumPy floor_divide, key = float32(score) - float32(j)/(2*max_samples)),
+ * then greedy NMS on the final predicted point (keep while fewer than best_of are kept and no
+ * kept candidate is closer than nms_thresh); new list = kept ++ dropped.
+ * Replaces StimulusVerification/verify_predictions.py:251-277.
+ *   pred [n, mtot, t, 2]; scores [n, mtot] float32 (scores_f64 = 0) or float64 (= 1)
+ *   order [n, max_samples] int32 out: original index of the candidate at each new position
+ *   n_selected [n] int32 out (may be NULL): number of kept candidates (<= best_of)
+ * max_samples <= min(mtot, 1024). */
+int mtp_nms_rerank_f32(const float *pred, const void *scores, int scores_f64, int64_t n, int mtot, int t,
+                       int max_samples, int best_of, double bin_size, double nms_thresh, int32_t *order,
+                       int32_t *n_selected, void *stream);
+int mtp_nms_rerank_f64(const double *pred, const void *scores, int scores_f64, int64_t n, int mtot, int t,
+                       int max_samples, int best_of, double bin_size, double nms_thresh, int32_t *order,
+                       int32_t *n_selected, void *stream);
+
+/* out[a, p] = pred[a, order[a, p]] (p < m), out[a, p] = pred[a, p] (m <= p < mtot): the
+ * re-ordered copy verify_predictions.py:277 builds.  order [n, m]; out must not alias pred. */
+int mtp_gather_candidates_f32(const float *pred, const int32_t *order, int64_t n, int mtot, int m, int t, float *out,
+                              void *stream);
+int mtp_gather_candidates_f64(const double *pred, const int32_t *order, int64_t n, int mtot, int m, int t, double *out,
+                              void *stream);
+
+/* mtp_best_of_k_* over the re-ranked list without materialising it: candidate c of agent a is
+ * pred[a, order[a*ostride + c]] (verify_predictions.py:280-290); idx / idx2 are positions c. */
+int mtp_best_of_k_reranked_f32(const float *pred, const float *gt, const int32_t *order, int ostride, int64_t n, int k,
+                               int kstride, int t, float ade_div, int mode, float *min_ade, float *min_fde,
+                               int32_t *idx, int32_t *idx2, double *sums, void *stream);
+int mtp_best_of_k_reranked_f64(const double *pred, const double *gt, const int32_t *order, int ostride, int64_t n,
+                               int k, int kstride, int t, double ade_div, int mode, double *min_ade, double *min_fde,
+                               int32_t *idx, int32_t *idx2, double *sums, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,94 @@
+// Decode glue around the best-of-K evaluation on gfx950.
+//
+// Replaces, for all candidates of all agents in one launch,
+//   PCCSNet/utils/data_process.py:111-122   transform_trajectory: in-place prefix sum over time
+//   PCCSNet/train_steps.py:253-255          gen_prediction: rotate back with the per-agent 2x2
+//                                           matrix (torch.bmm) and add the last observed position
+// The output layout [n, k, t, 2] float32 is the wire format of all_output_<ds>_top<k>.npy
+// (train_steps.py:257-262), which StimulusVerification/verify_predictions.py:52-54 reads back.
+//
+// HBM-bound: N*K*T*2*4 bytes read + the same written.  One thread per candidate; the prefix
+// sum is sequential in time (p_j = d_j + p_{j-1}, float adds in the reference's order, so the
+// cumulative positions are bit-identical to torch's), 16-byte loads/stores when t is even.
+#include "mtp_internal.h"
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_decode_trajectories(const float *disp, int64_t n, int k, int t,
+                                                             const float *__restrict__ rot,
+                                                             const float *__restrict__ last_obs, float *out) {
+    const int64_t total = n * k;
+    const size_t ts = (size_t)t * 2;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = c / k;
+        float m00 = 1.f, m01 = 0.f, m10 = 0.f, m11 = 1.f, lx = 0.f, ly = 0.f;
+        if (rot != nullptr) {
+            const float4 m = *reinterpret_cast<const float4 *>(rot + a * 4);
+            m00 = m.x; m01 = m.y; m10 = m.z; m11 = m.w;
+        }
+        if (last_obs != nullptr) {
+            lx = last_obs[a * 2];
+            ly = last_obs[a * 2 + 1];
+        }
+        const float *p = disp + (size_t)c * ts;
+        float *o = out + (size_t)c * ts;
+        float cx = 0.f, cy = 0.f;
+        auto emit = [&](float x, float y, float &ox, float &oy) {
+            // running sum, then out = M @ p (+ last_obs); products and sums rounded separately
+            cx = x + cx;
+            cy = y + cy;
+            ox = cx;
+            oy = cy;
+            if (rot != nullptr) {
+                ox = m00 * cx + m01 * cy;
+                oy = m10 * cx + m11 * cy;
+            }
+            if (last_obs != nullptr) {
+                ox = ox + lx;
+                oy = oy + ly;
+            }
+        };
+        if (VEC) {
+            const float4 *pv = reinterpret_cast<const float4 *>(p);
+            float4 *ov = reinterpret_cast<float4 *>(o);
+            const int half = t >> 1;
+#pragma unroll 6
+            for (int q = 0; q < half; ++q) {
+                const float4 v = pv[q];
+                float4 w;
+                emit(v.x, v.y, w.x, w.y);
+                emit(v.z, v.w, w.z, w.w);
+                ov[q] = w;
+            }
+        } else {
+            for (int q = 0; q < t; ++q) {
+                float ox, oy;
+                emit(p[2 * q], p[2 * q + 1], ox, oy);
+                o[2 * q] = ox;
+                o[2 * q + 1] = oy;
+            }
+        }
+    }
+}
+
+extern "C" int mtp_decode_trajectories_f32(const float *disp, int64_t n, int k, int t, const float *rot,
+                                           const float *last_obs, float *out, void *stream) {
+    MTP_REQUIRE(n >= 0 && k >= 1 && t >= 1, "mtp_decode_trajectories: bad shape n=%lld k=%d t=%d", (long long)n, k, t);
+    if (n == 0) return MTP_OK;
+    MTP_REQUIRE(disp && out, "mtp_decode_trajectories: null pointer");
+    MTP_REQUIRE(rot == nullptr || reinterpret_cast<uintptr_t>(rot) % 16 == 0,
+                "mtp_decode_trajectories: rotation matrices must be 16-byte aligned");
+    const int64_t total = n * k;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const bool vec = (t % 2 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+    hipStream_t s = mtp_stream(stream);
+    if (vec)
+        hipLaunchKernelGGL(k_decode_trajectories<true>, dim3((unsigned)blocks), dim3(256), 0, s, disp, n, k, t, rot,
+                           last_obs, out);
+    else
+        hipLaunchKernelGGL(k_decode_trajectories<false>, dim3((unsigned)blocks), dim3(256), 0, s, disp, n, k, t, rot,
+                           last_obs, out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}

@@ -39,11 +39,15 @@ __device__ __forceinline__ double tsqrt<double>(double v) {
 }
 
 // One candidate: returns (sum_t dist_t, dist_T).  VEC = true when t is even and the
-// trajectories are 4-element aligned, so two time steps travel per load.
-template <typename T, bool VEC>
+// trajectories are 4-element aligned, so two time steps travel per load.  DISP = true: `p` holds
+// the network's per-step displacements and the positions are their running sum in time order,
+// p_j = d_j + p_{j-1} in T arithmetic -- transform_trajectory (PCCSNet/utils/data_process.py:111-122)
+// fused into the scoring pass, so the decoded trajectories are never written.
+template <typename T, bool VEC, bool DISP>
 __device__ __forceinline__ void candidate_dists(const T *__restrict__ p, const T *__restrict__ g, int t, T &sum,
                                                 T &last) {
     T s = 0, l = 0;
+    T cx = 0, cy = 0;
     if (VEC) {
         typedef typename Vec4<T>::type V;
         const V *pv = reinterpret_cast<const V *>(p);
@@ -51,7 +55,16 @@ __device__ __forceinline__ void candidate_dists(const T *__restrict__ p, const T
         const int half = t >> 1;
 #pragma unroll 6
         for (int q = 0; q < half; ++q) {
-            const V a = pv[q], b = gv[q];
+            V a = pv[q];
+            const V b = gv[q];
+            if (DISP) {
+                a.x = a.x + cx;
+                a.y = a.y + cy;
+                a.z = a.z + a.x;
+                a.w = a.w + a.y;
+                cx = a.z;
+                cy = a.w;
+            }
             const T dx0 = b.x - a.x, dy0 = b.y - a.y, dx1 = b.z - a.z, dy1 = b.w - a.w;
             const T d0 = tsqrt<T>(dx0 * dx0 + dy0 * dy0);
             l = tsqrt<T>(dx1 * dx1 + dy1 * dy1);
@@ -59,7 +72,14 @@ __device__ __forceinline__ void candidate_dists(const T *__restrict__ p, const T
         }
     } else {
         for (int q = 0; q < t; ++q) {
-            const T dx = g[2 * q] - p[2 * q], dy = g[2 * q + 1] - p[2 * q + 1];
+            T ax = p[2 * q], ay = p[2 * q + 1];
+            if (DISP) {
+                ax = ax + cx;
+                ay = ay + cy;
+                cx = ax;
+                cy = ay;
+            }
+            const T dx = g[2 * q] - ax, dy = g[2 * q + 1] - ay;
             l = tsqrt<T>(dx * dx + dy * dy);
             s = s + l;
         }
@@ -76,10 +96,14 @@ __device__ __forceinline__ void lexmin(T &v, int &i, T ov, int oi) {
     }
 }
 
-// grid-stride over groups of `apb` agents; 256 threads.
-template <typename T, bool VEC>
+// grid-stride over groups of `apb` agents; 256 threads.  order (NULL or [n, ostride] int32):
+// candidate c of agent a is pred[a, order[a, c]] -- the re-ranked candidate list of
+// verify_predictions.py:277-280 scored without materialising the re-ordered tensor; the
+// reported indices are positions c in that list.
+template <typename T, bool VEC, bool DISP>
 __global__ __launch_bounds__(256) void k_best_of_k(const T *__restrict__ pred, const T *__restrict__ gt, int64_t n,
                                                    int k, int kstride, int t, T ade_div, int mode, int apb,
+                                                   const int32_t *__restrict__ order, int ostride,
                                                    T *min_ade, T *min_fde, int32_t *idx, int32_t *idx2,
                                                    double *sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -95,10 +119,11 @@ __global__ __launch_bounds__(256) void k_best_of_k(const T *__restrict__ pred, c
         // phase 1: per-candidate (ADE, FDE) -> LDS
         for (int c = tid; c < na * k; c += 256) {
             const int a = c / k, cand = c - a * k;
-            const T *p = pred + ((size_t)(a0 + a) * kstride + cand) * tstride;
+            const int src = order ? order[(size_t)(a0 + a) * ostride + cand] : cand;
+            const T *p = pred + ((size_t)(a0 + a) * kstride + src) * tstride;
             const T *g = gt + (size_t)(a0 + a) * tstride;
             T s, l;
-            candidate_dists<T, VEC>(p, g, t, s, l);
+            candidate_dists<T, VEC, DISP>(p, g, t, s, l);
             s_ade[c] = s / ade_div;
             s_fde[c] = l;
         }
@@ -164,7 +189,7 @@ __global__ __launch_bounds__(256) void k_ade_fde(const T *__restrict__ pred, con
         const int64_t a = c / k;
         const int cand = (int)(c - a * k);
         T s, l;
-        candidate_dists<T, VEC>(pred + ((size_t)a * kstride + cand) * tstride, gt + (size_t)a * tstride, t, s, l);
+        candidate_dists<T, VEC, false>(pred + ((size_t)a * kstride + cand) * tstride, gt + (size_t)a * tstride, t, s, l);
         ade[c] = s / ade_div;
         fde[c] = l;
     }
@@ -172,10 +197,12 @@ __global__ __launch_bounds__(256) void k_ade_fde(const T *__restrict__ pred, con
 
 template <typename T>
 static int best_of_k_impl(const T *pred, const T *gt, int64_t n, int k, int kstride, int t, T ade_div, int mode,
-                          T *min_ade, T *min_fde, int32_t *idx, int32_t *idx2, double *sums, void *stream) {
+                          bool disp, const int32_t *order, int ostride, T *min_ade, T *min_fde, int32_t *idx,
+                          int32_t *idx2, double *sums, void *stream) {
     MTP_REQUIRE(n >= 0 && k >= 1 && kstride >= k && t >= 1, "mtp_best_of_k: bad shape n=%lld k=%d kstride=%d t=%d",
                 (long long)n, k, kstride, t);
     MTP_REQUIRE(mode >= 0 && mode <= 2, "mtp_best_of_k: mode must be 0, 1 or 2 (got %d)", mode);
+    MTP_REQUIRE(order == nullptr || ostride >= k, "mtp_best_of_k: order stride %d < k=%d", ostride, k);
     if (n == 0) return MTP_OK;
     MTP_REQUIRE(pred && gt, "mtp_best_of_k: null input");
     const size_t per_agent = 2 * (size_t)k * sizeof(T);
@@ -188,12 +215,18 @@ static int best_of_k_impl(const T *pred, const T *gt, int64_t n, int k, int kstr
     const unsigned grid = (unsigned)(n_groups < 256 * 8 ? n_groups : 256 * 8);
     const bool vec = (t % 2 == 0) && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(gt)) % (4 * sizeof(T)) == 0);
     hipStream_t s = mtp_stream(stream);
-    if (vec)
-        hipLaunchKernelGGL((k_best_of_k<T, true>), dim3(grid), dim3(256), lds, s, pred, gt, n, k, kstride, t, ade_div, mode,
-                           apb, min_ade, min_fde, idx, idx2, sums);
+#define MTP_BOK_LAUNCH(VEC, DISP)                                                                                   \
+    hipLaunchKernelGGL((k_best_of_k<T, VEC, DISP>), dim3(grid), dim3(256), lds, s, pred, gt, n, k, kstride, t, ade_div, \
+                       mode, apb, order, ostride, min_ade, min_fde, idx, idx2, sums)
+    if (vec && disp)
+        MTP_BOK_LAUNCH(true, true);
+    else if (vec)
+        MTP_BOK_LAUNCH(true, false);
+    else if (disp)
+        MTP_BOK_LAUNCH(false, true);
     else
-        hipLaunchKernelGGL((k_best_of_k<T, false>), dim3(grid), dim3(256), lds, s, pred, gt, n, k, kstride, t, ade_div,
-                           mode, apb, min_ade, min_fde, idx, idx2, sums);
+        MTP_BOK_LAUNCH(false, false);
+#undef MTP_BOK_LAUNCH
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
@@ -201,13 +234,40 @@ static int best_of_k_impl(const T *pred, const T *gt, int64_t n, int k, int kstr
 extern "C" int mtp_best_of_k_f32(const float *pred, const float *gt, int64_t n, int k, int kstride, int t, float ade_div,
                                  int mode, float *min_ade, float *min_fde, int32_t *idx, int32_t *idx2, double *sums,
                                  void *stream) {
-    return best_of_k_impl<float>(pred, gt, n, k, kstride, t, ade_div, mode, min_ade, min_fde, idx, idx2, sums, stream);
+    return best_of_k_impl<float>(pred, gt, n, k, kstride, t, ade_div, mode, false, nullptr, 0, min_ade, min_fde, idx,
+                                 idx2, sums, stream);
 }
 
 extern "C" int mtp_best_of_k_f64(const double *pred, const double *gt, int64_t n, int k, int kstride, int t,
                                  double ade_div, int mode, double *min_ade, double *min_fde, int32_t *idx,
                                  int32_t *idx2, double *sums, void *stream) {
-    return best_of_k_impl<double>(pred, gt, n, k, kstride, t, ade_div, mode, min_ade, min_fde, idx, idx2, sums, stream);
+    return best_of_k_impl<double>(pred, gt, n, k, kstride, t, ade_div, mode, false, nullptr, 0, min_ade, min_fde, idx,
+                                  idx2, sums, stream);
+}
+
+extern "C" int mtp_best_of_k_disp_f32(const float *disp, const float *gt, int64_t n, int k, int kstride, int t,
+                                      float ade_div, int mode, float *min_ade, float *min_fde, int32_t *idx,
+                                      int32_t *idx2, double *sums, void *stream) {
+    return best_of_k_impl<float>(disp, gt, n, k, kstride, t, ade_div, mode, true, nullptr, 0, min_ade, min_fde, idx,
+                                 idx2, sums, stream);
+}
+
+extern "C" int mtp_best_of_k_reranked_f32(const float *pred, const float *gt, const int32_t *order, int ostride,
+                                          int64_t n, int k, int kstride, int t, float ade_div, int mode,
+                                          float *min_ade, float *min_fde, int32_t *idx, int32_t *idx2, double *sums,
+                                          void *stream) {
+    MTP_REQUIRE(order != nullptr, "mtp_best_of_k_reranked: order is NULL");
+    return best_of_k_impl<float>(pred, gt, n, k, kstride, t, ade_div, mode, false, order, ostride, min_ade, min_fde,
+                                 idx, idx2, sums, stream);
+}
+
+extern "C" int mtp_best_of_k_reranked_f64(const double *pred, const double *gt, const int32_t *order, int ostride,
+                                          int64_t n, int k, int kstride, int t, double ade_div, int mode,
+                                          double *min_ade, double *min_fde, int32_t *idx, int32_t *idx2,
+                                          double *sums, void *stream) {
+    MTP_REQUIRE(order != nullptr, "mtp_best_of_k_reranked: order is NULL");
+    return best_of_k_impl<double>(pred, gt, n, k, kstride, t, ade_div, mode, false, order, ostride, min_ade, min_fde,
+                                  idx, idx2, sums, stream);
 }
 
 extern "C" int mtp_ade_fde_f32(const float *pred, const float *gt, int64_t n, int k, int kstride, int t, float ade_div,

@@ -216,3 +216,125 @@ def ade_fde(pred, gt, ade_div=1.0, best_of=None):
         check(lib().mtp_ade_fde_f32(ptr(pred), ptr(gt), n, k, ktot, t, float(ade_div), ptr(ade), ptr(fde),
                                     stream_ptr()), "mtp_ade_fde_f32")
     return ade, fde
+
+
+# ------------------------------------------------------------------------------------------
+# decode glue (f3) and NMS re-ranking (f4)
+# ------------------------------------------------------------------------------------------
+def decode_trajectories(disp, rot=None, last_obs=None, out=None):
+    """Prefix sum over time of float32 displacements [N, K, T, 2] (+ rotate back with rot
+    [N, 2, 2] + add last_obs [N, 2]).  ``out=disp`` decodes in place."""
+    _req(disp, "disp", torch.float32, 4, align=4)
+    n, k, t, two = disp.shape
+    if two != 2:
+        raise ValueError(f"disp: expected [N, K, T, 2], got {tuple(disp.shape)}")
+    if rot is not None:
+        _req(rot, "rot", torch.float32, 3)
+        if tuple(rot.shape) != (n, 2, 2):
+            raise ValueError(f"rot: expected {(n, 2, 2)}, got {tuple(rot.shape)}")
+    if last_obs is not None:
+        _req(last_obs, "last_obs", torch.float32, 2, align=4)
+        if tuple(last_obs.shape) != (n, 2):
+            raise ValueError(f"last_obs: expected {(n, 2)}, got {tuple(last_obs.shape)}")
+    if out is None:
+        out = torch.empty_like(disp)
+    _req(out, "out", torch.float32, 4, align=4)
+    assert out.shape == disp.shape
+    with torch.cuda.device(disp.device):
+        check(lib().mtp_decode_trajectories_f32(ptr(disp), n, k, t, ptr(rot), ptr(last_obs), ptr(out), stream_ptr()),
+              "mtp_decode_trajectories_f32")
+    return out
+
+
+def best_of_k_disp(disp, gt, mode=0, ade_div=None, want_per_agent=True):
+    """best_of_k on raw per-step displacements [N, K, T, 2] (float32): transform_trajectory is
+    fused into the scoring pass."""
+    _req(disp, "disp", torch.float32, 4, align=4)
+    _req(gt, "gt", torch.float32, 3, align=4)
+    n, k, t, two = disp.shape
+    if two != 2 or tuple(gt.shape) != (n, t, 2):
+        raise ValueError(f"shape mismatch: disp {tuple(disp.shape)}, gt {tuple(gt.shape)}")
+    if mode not in (0, 1, 2):
+        raise ValueError(f"mode must be 0, 1 or 2 (got {mode})")
+    if ade_div is None:
+        ade_div = t
+    dev = disp.device
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    if want_per_agent:
+        min_ade = torch.empty(n, dtype=torch.float32, device=dev)
+        min_fde = torch.empty(n, dtype=torch.float32, device=dev)
+        idx = torch.empty(n, dtype=torch.int32, device=dev)
+        idx2 = torch.empty(n, dtype=torch.int32, device=dev)
+    else:
+        min_ade = min_fde = idx = idx2 = None
+    with torch.cuda.device(dev):
+        check(lib().mtp_best_of_k_disp_f32(ptr(disp), ptr(gt), n, k, k, t, float(ade_div), int(mode), ptr(min_ade),
+                                           ptr(min_fde), ptr(idx), ptr(idx2), ptr(sums), stream_ptr()),
+              "mtp_best_of_k_disp_f32")
+    return dict(min_ade=min_ade, min_fde=min_fde, idx=idx, idx2=idx2, sums=sums)
+
+
+def nms_rerank(pred, scores, max_samples, best_of, bin_size, nms_thresh):
+    """order int32 [N, max_samples], n_selected int32 [N] (device) for pred [N, Mtot, T, 2]
+    (float32 / float64) and scores [N, Mtot] (float32 / float64)."""
+    if pred.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"pred: expected float32 or float64, got {pred.dtype}")
+    if scores.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"scores: expected float32 or float64, got {scores.dtype}")
+    _req(pred, "pred", pred.dtype, 4, align=pred.element_size())
+    _req(scores, "scores", scores.dtype, 2, align=scores.element_size())
+    n, mtot, t, two = pred.shape
+    if two != 2 or tuple(scores.shape) != (n, mtot):
+        raise ValueError(f"shape mismatch: pred {tuple(pred.shape)}, scores {tuple(scores.shape)}")
+    if not (1 <= max_samples <= min(mtot, 1024)):
+        raise ValueError(f"max_samples={max_samples} must be in [1, min({mtot}, 1024)]")
+    order = torch.empty((n, max_samples), dtype=torch.int32, device=pred.device)
+    n_sel = torch.empty(n, dtype=torch.int32, device=pred.device)
+    fn = lib().mtp_nms_rerank_f32 if pred.dtype == torch.float32 else lib().mtp_nms_rerank_f64
+    with torch.cuda.device(pred.device):
+        check(fn(ptr(pred), ptr(scores), int(scores.dtype == torch.float64), n, mtot, t, int(max_samples), int(best_of),
+                 float(bin_size), float(nms_thresh), ptr(order), ptr(n_sel), stream_ptr()), "mtp_nms_rerank")
+    return order, n_sel
+
+
+def gather_candidates(pred, order):
+    """Re-ordered copy: out[a, p] = pred[a, order[a, p]] for p < order.shape[1], rest unchanged."""
+    _req(pred, "pred", pred.dtype, 4)
+    _req(order, "order", torch.int32, 2, align=4)
+    n, mtot, t, _ = pred.shape
+    m = order.shape[1]
+    if order.shape[0] != n or m > mtot:
+        raise ValueError(f"order {tuple(order.shape)} does not fit pred {tuple(pred.shape)}")
+    out = torch.empty_like(pred)
+    fn = lib().mtp_gather_candidates_f32 if pred.dtype == torch.float32 else lib().mtp_gather_candidates_f64
+    with torch.cuda.device(pred.device):
+        check(fn(ptr(pred), ptr(order), n, mtot, m, t, ptr(out), stream_ptr()), "mtp_gather_candidates")
+    return out
+
+
+def best_of_k_reranked(pred, gt, order, mode=0, ade_div=None, best_of=None):
+    """best_of_k over the first ``best_of`` positions of the re-ranked list given by ``order``."""
+    if pred.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"pred: expected float32 or float64, got {pred.dtype}")
+    _req(pred, "pred", pred.dtype, 4, align=pred.element_size())
+    _req(gt, "gt", pred.dtype, 3, align=pred.element_size())
+    _req(order, "order", torch.int32, 2, align=4)
+    n, ktot, t, two = pred.shape
+    if two != 2 or tuple(gt.shape) != (n, t, 2) or order.shape[0] != n:
+        raise ValueError(f"shape mismatch: pred {tuple(pred.shape)}, gt {tuple(gt.shape)}, order {tuple(order.shape)}")
+    k = order.shape[1] if best_of is None else int(best_of)
+    if not (1 <= k <= order.shape[1]):
+        raise ValueError(f"best_of={k} must be in [1, {order.shape[1]}]")
+    if ade_div is None:
+        ade_div = t
+    dev = pred.device
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    min_ade = torch.empty(n, dtype=pred.dtype, device=dev)
+    min_fde = torch.empty(n, dtype=pred.dtype, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    idx2 = torch.empty(n, dtype=torch.int32, device=dev)
+    fn = lib().mtp_best_of_k_reranked_f32 if pred.dtype == torch.float32 else lib().mtp_best_of_k_reranked_f64
+    with torch.cuda.device(dev):
+        check(fn(ptr(pred), ptr(gt), ptr(order), order.shape[1], n, k, ktot, t, float(ade_div), int(mode), ptr(min_ade),
+                 ptr(min_fde), ptr(idx), ptr(idx2), ptr(sums), stream_ptr()), "mtp_best_of_k_reranked")
+    return dict(min_ade=min_ade, min_fde=min_fde, idx=idx, idx2=idx2, sums=sums)

@@ -45,3 +45,46 @@ def make_trajectories(seed, n, k, t, step=1200, noise=800, dtype=np.float32, sca
     gt = (gt.astype(np.float64) / _Q * scale).astype(dtype)
     pred = (pred.astype(np.float64) / _Q * scale).astype(dtype)
     return np.ascontiguousarray(pred), np.ascontiguousarray(gt)
+
+
+def make_scene_trajectories(seed, n, t=20, extent=6, step=700, still_every=9, dtype=np.float32):
+    """[n, t, 2] absolute positions of pedestrians sharing one scene (metres, exact dyadics):
+    random start inside an ``extent`` x ``extent`` square, one of four common "flows" (mean step)
+    per pedestrian plus jitter, so that many neighbours pass the speed / angle filter.
+    Every ``still_every``-th pedestrian stands still (speed exactly 0) and every 13th repeats the
+    pedestrian before it (identical speed and angle) -- the cases the neighbour predicate of
+    PCCSNet/utils/data_process.py:148-158 treats specially."""
+    rs = np.random.RandomState(seed)
+    start = rs.randint(0, extent * 4096 + 1, size=(n, 1, 2))
+    flows = rs.randint(-step, step + 1, size=(4, 1, 2))
+    mean = flows[rs.randint(0, 4, size=n)] + rs.randint(-step // 16, step // 16 + 1, size=(n, 1, 2))
+    jit = rs.randint(-step // 8, step // 8 + 1, size=(n, t, 2))
+    steps = mean + jit
+    steps[::still_every] = 0
+    pos = start + np.cumsum(steps, axis=1)
+    for i in range(13, n, 13):
+        pos[i] = pos[i - 1] + rs.randint(-2000, 2001, size=(1, 2))  # same motion, shifted a little
+    return np.ascontiguousarray((pos.astype(np.float64) / _Q).astype(dtype))
+
+
+def make_displacements(seed, n, k, t, step=900, dtype=np.float32):
+    """[n, k, t, 2] per-step displacements like the decoder's raw output (exact dyadics)."""
+    rs = np.random.RandomState(seed)
+    d = rs.randint(-step, step + 1, size=(n, k, t, 2))
+    return np.ascontiguousarray((d.astype(np.float64) / _Q).astype(dtype))
+
+
+def make_candidate_sets(seed, n, m, t, n_modes=9, dtype=np.float64):
+    """Stored prediction sets for the re-ranking step: pred [n, m, t, 2] drawn around ``n_modes``
+    futures per agent (so many candidates end within the NMS radius of each other), gt future
+    [n, t, 2], verification scores [n, m] float32 with heavy ties after binning."""
+    rs = np.random.RandomState(seed)
+    modes = np.cumsum(rs.randint(-1500, 1501, size=(n, n_modes, t, 2)), axis=2)
+    z = rs.randint(0, n_modes, size=(n, m))
+    e = rs.randint(-500, 501, size=(n, m, t, 2))
+    pred = modes[np.arange(n)[:, None], z] + e
+    gt = modes[:, 0] + rs.randint(-300, 301, size=(n, t, 2))
+    scores = rs.randint(-60 * 8, 20 * 8 + 1, size=(n, m)).astype(np.float64) / 8.0
+    return (np.ascontiguousarray((pred.astype(np.float64) / _Q).astype(dtype)),
+            np.ascontiguousarray((gt.astype(np.float64) / _Q).astype(dtype)),
+            np.ascontiguousarray(scores.astype(np.float32)))

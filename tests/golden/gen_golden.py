@@ -201,12 +201,130 @@ def gen_g8():
          labels=labels, sizes=sizes)
 
 
+def _import_data_process():
+    """PCCSNet/utils/data_process.py under a clean ``utils`` namespace."""
+    for m in [m for m in sys.modules if m == "utils" or m.startswith("utils.")]:
+        del sys.modules[m]
+    path = os.path.join(REF, "PCCSNet")
+    sys.path.insert(0, path)
+    try:
+        return importlib.import_module("utils.data_process")
+    finally:
+        sys.path.remove(path)
+
+
+def gen_g10():
+    """f3: transform_trajectory (imported) and gen_prediction's rotate-back (train_steps.py:253-255,
+    evaluated with the same torch calls per agent; train_steps.py itself needs a GPU to import-run)."""
+    dp = _import_data_process()
+    n, k, t = 48, 20, 12
+    disp = datagen.make_displacements(61, n, k, t)
+    rs = np.random.RandomState(62)
+    theta = rs.randint(-3141, 3142, size=n) / 1000.0
+    rot = np.stack([np.stack([np.cos(theta), -np.sin(theta)], -1), np.stack([np.sin(theta), np.cos(theta)], -1)], 1)
+    rot = torch.tensor(rot).float()
+    last_obs = torch.from_numpy((rs.randint(-40000, 40001, size=(n, 2)) / 4096.0).astype(np.float32))
+    cum4 = dp.transform_trajectory(torch.from_numpy(disp.copy())).numpy()
+    cum3 = dp.transform_trajectory(torch.from_numpy(disp[:, 0].copy())).numpy()
+    full = []
+    for i in range(n):
+        net_output = dp.transform_trajectory(torch.from_numpy(disp[i].copy()))
+        mat = rot[i:i + 1]
+        output = torch.bmm(mat.repeat(k, 1, 1), net_output.transpose(1, 2)).transpose(1, 2)
+        output += last_obs[i:i + 1].unsqueeze(0)
+        full.append(output.cpu().numpy())
+    full = np.stack(full)
+    assert full.shape == (n, k, t, 2) and full.dtype == np.float32
+    save("g10_decode", seed=61, n=n, k=k, t=t, rot=rot.numpy(), last_obs=last_obs.numpy(), cum4=cum4, cum3=cum3,
+         decoded=full)
+
+
+def gen_g11():
+    """f4: verify_predictions.py:251-290 (top-level script, not importable): its re-ranking loop and
+    the "After Verification" evaluation evaluated with the same torch / NumPy calls, on float64 and
+    float32 prediction sets; the composed permutation is tracked beside the data."""
+    n, m_tot, t, best_of, bin_size, nms_thresh = 24, 200, 12, 20, 2, 0.3
+    out = {}
+    for tag, dtype, max_samples in (("f64", np.float64, 200), ("f32", np.float32, 150)):
+        pred, fut, scores = datagen.make_candidate_sets(71, n, m_tot, t, dtype=dtype)
+        work = pred.copy()
+        order = np.empty((n, max_samples), dtype=np.int32)
+        n_sel = np.empty(n, dtype=np.int32)
+        for i in range(n):
+            vs = scores[i][:max_samples] // bin_size
+            vs = torch.tensor(vs).float() - torch.arange(0, len(vs)).float() / (2 * len(vs))
+            srt = torch.argsort(vs, descending=True).tolist()
+            assert len(set(vs.tolist())) == len(vs)  # no ties: the order is well defined
+            work[i, :max_samples] = work[i, :max_samples][srt]
+            selected, ignored = [0], []
+            for idx in range(1, max_samples):
+                if len(selected) >= best_of:
+                    ignored.append(idx)
+                else:
+                    dd = np.linalg.norm(work[i, selected] - work[i, idx:idx + 1], axis=-1)[..., -1]
+                    (ignored if np.min(dd) < nms_thresh else selected).append(idx)
+            new_order = selected + ignored
+            work[i, :max_samples] = work[i, :max_samples][new_order]
+            order[i] = np.asarray(srt)[new_order]
+            n_sel[i] = len(selected)
+        assert all(np.array_equal(work[i, :max_samples], pred[i][order[i]]) for i in range(n))
+        res = {}
+        for fde_prio in (False, True):
+            diff = np.linalg.norm(work[:, :best_of] - fut[:, None], axis=-1)
+            tot_a = tot_f = 0
+            for i in range(n):
+                j = np.argmin(diff[i, :, -1]) if fde_prio else np.argmin(np.sum(diff[i], axis=-1))
+                tot_f += diff[i, j, -1]
+                tot_a += np.sum(diff[i, j])
+            p = "fdeprio" if fde_prio else "adeprio"
+            res[f"{tag}_{p}_ade"] = tot_a / n / t
+            res[f"{tag}_{p}_fde"] = tot_f / n
+        out.update(res)
+        out[f"{tag}_order"] = order
+        out[f"{tag}_n_sel"] = n_sel
+        out[f"{tag}_max_samples"] = max_samples
+    save("g11_nms_rerank", seed=71, n=n, m_tot=m_tot, t=t, best_of=best_of, bin_size=bin_size, nms_thresh=nms_thresh,
+         **out)
+
+
+def gen_g12():
+    """f2: process_scene and gen_prob imported from PCCSNet/utils/data_process.py; the dense soft
+    labels of get_scene_data (:212-218) from their outputs (get_scene_data itself does
+    np.array() on ragged lists, which NumPy >= 1.24 refuses)."""
+    import tempfile
+    dp = _import_data_process()
+    sizes = [230, 1, 170, 199]
+    trj = np.concatenate([datagen.make_scene_trajectories(81 + i, s) for i, s in enumerate(sizes)])
+    split_marks = [0] + list(np.cumsum(sizes))
+    n, K = len(trj), 24
+    labels = np.random.RandomState(85).randint(0, K, size=n).astype(np.int32)
+    args = argparse.Namespace(obs_len=8, pred_len=12, data_from="ethucy", rad=1.0, n_cluster=K)
+    train_set = argparse.Namespace(trj_data=torch.from_numpy(trj).float(), split_marks=split_marks)
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "ethucy", "toy"))
+        scene = dp.process_scene("toy", train_set, args, save_dir=tmp)
+        res_class, res_prob = dp.gen_prob(scene, labels, tmp)
+    dense = np.zeros((n, K)).astype(float)
+    for i in range(n):
+        dense[i][res_class[i]] = res_prob[i]
+    nb_off = np.zeros(n + 1, dtype=np.int64)
+    nb_off[1:] = np.cumsum([len(scene[i]) for i in range(n)])
+    nb_ids = np.asarray([j for i in range(n) for j in scene[i]], dtype=np.int64)
+    cl_off = np.zeros(n + 1, dtype=np.int64)
+    cl_off[1:] = np.cumsum([len(c) for c in res_class])
+    assert nb_off[-1] > 1500 and (np.diff(nb_off) == 0).any()
+    save("g12_scene_soft_labels", seeds=np.asarray([81 + i for i in range(len(sizes))]), sizes=np.asarray(sizes),
+         split_marks=np.asarray(split_marks), obs_len=8, rad=1.0, K=K, labels=labels, nb_off=nb_off, nb_ids=nb_ids,
+         cl_off=cl_off, classes=np.concatenate(res_class).astype(np.int64), probs=np.concatenate(res_prob),
+         dense=dense)
+
+
 if __name__ == "__main__":
     warnings.simplefilter("error")  # a ConvergenceWarning here means a bad fixture
     utility, metrics = _import_ref("PCCSNet")
     only = sys.argv[1:]
     jobs = dict(g1=lambda: gen_g1(utility), g2=lambda: gen_g2(utility), g45=gen_g4_g5,
-                g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8)
+                g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()
