@@ -240,6 +240,30 @@ int mtp_best_of_k_reranked_f64(const double *pred, const double *gt, const int32
                                int k, int kstride, int t, double ade_div, int mode, double *min_ade, double *min_fde,
                                int32_t *idx, int32_t *idx2, double *sums, void *stream);
 
+/* ---- modality-loss soft labels (section 8, row f2) ---- */
+
+/* last[i] = trj[i, t, :] (float32) and speed_angle[i] = cmath.polar(trj[i, t] - trj[i, 0]) in double
+ * (the offset is a float32 subtraction).  trj [n, tlen, 2].
+ * Replaces get_speed_and_angle, PCCSNet/utils/data_process.py:125-131 (+ last_coords, :140). */
+int mtp_speed_angle_f32(const float *trj, int64_t n, int tlen, int t, float *last, double *speed_angle, void *stream);
+
+/* Scene neighbour search, PCCSNet/utils/data_process.py:143-160: j is a neighbour of i when both are
+ * in the same scene, j != i, ||last_i - last_j|| <= rad (float32) and (both speeds are 0, or
+ * 0.9 s_i < s_j < 1.1 s_i and the heading difference, wrapped to [0, pi], is < 0.1 pi).
+ *   scene_of [n] int32 scene index of each sample; split_marks [n_scenes + 1] int64 (device)
+ * Two passes build the CSR lists in ascending j (the reference's order):
+ *   count pass: counts != NULL, offsets = ids = NULL  -> counts[i]
+ *   fill pass:  counts == NULL, offsets [n] (exclusive prefix of counts), ids [sum counts] int64 */
+int mtp_scene_neighbors_f32(const float *last, const double *speed_angle, const int32_t *scene_of,
+                            const int64_t *split_marks, int64_t n, double rad, int64_t *counts, const int64_t *offsets,
+                            int64_t *ids, void *stream);
+
+/* dense[i, c] = (#neighbours of i with label c + [c == labels[i]]) / (len(neighbours) + 1), float64
+ * [n, k], every element written.  offsets [n + 1], ids: the CSR lists above; labels [n] in [0, k).
+ * Replaces gen_prob + the dense fill of get_scene_data, data_process.py:172-187, :212-218. */
+int mtp_soft_labels_f64(const int64_t *offsets, const int64_t *ids, const int32_t *labels, int64_t n, int k,
+                        double *dense, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,9 @@ SIGNATURES = {
     "mtp_best_of_k_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mtp_best_of_k_f64": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mtp_ade_fde_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "mtp_speed_angle_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "mtp_scene_neighbors_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp]),
+    "mtp_soft_labels_f64": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "mtp_decode_trajectories_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mtp_best_of_k_disp_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mtp_nms_rerank_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _vp, _vp]),

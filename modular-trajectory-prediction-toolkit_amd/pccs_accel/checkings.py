@@ -24,3 +24,10 @@ def check_cluster_consistency(save_dir, size_array, args):
     if len(size_array) != args.n_cluster:
         return False
     return _ctime(save_dir, "cluster_result.npy") >= _ctime(save_dir, "memory.npy")
+
+
+def check_prob_consistency(save_dir, args):
+    """PCCSNet/utils/checkings.py:25-32: probabilities.pkl must not be older than cluster_result.npy."""
+    if args.no_time_check:
+        return True
+    return not (_ctime(save_dir, "cluster_result.npy") > _ctime(save_dir, "probabilities.pkl"))

@@ -1,2 +1,2 @@
-"""Drop-in for PCCSNet/utils/checkings.py:4-22 (the two checks the clustering cache uses)."""
-from ..checkings import check_cluster_consistency, check_memory_consistency  # noqa: F401
+"""Drop-in for PCCSNet/utils/checkings.py:4-32 (the checks the clustering / label caches use)."""
+from ..checkings import check_cluster_consistency, check_memory_consistency, check_prob_consistency  # noqa: F401

@@ -251,3 +251,76 @@ def test_rerank_argument_errors(gpu_device):
     order, _ = K.nms_rerank(pred, sc, 10, 20, 2, 0.3)
     # identical candidates: everything after the first is within the NMS radius -> kept = [0]
     assert order.cpu().tolist() == [list(range(10))] * 2
+
+
+# ---------------------------------------------------------------- f2
+def _g12_inputs(g):
+    return np.concatenate([datagen.make_scene_trajectories(int(s), int(n)) for s, n in zip(g["seeds"], g["sizes"])])
+
+
+def _classify_neighbour_mismatches(trj, split_marks, obs_len, rad, got, want):
+    """A neighbour may differ from the oracle's only where the device's hypot / atan2 rounding can
+    matter: speed ratio or wrapped heading difference within 1e-12 relative of its threshold."""
+    sa = G.speed_and_angle(trj, obs_len - 1)
+    bad = 0
+    for i in range(len(trj)):
+        for j in set(got[i]) ^ set(want[i]):
+            si, sj = sa[i, 0], sa[j, 0]
+            ad = abs(sa[i, 1] - sa[j, 1])
+            ad = min(ad, 2 * np.pi - ad)
+            near = [abs(sj - si * 0.9) <= 1e-12 * si, abs(sj - si * 1.1) <= 1e-12 * si, abs(ad - np.pi * 0.1) <= 1e-12]
+            bad += not any(near)
+    return bad
+
+
+def test_scene_neighbours_and_soft_labels_golden(gpu_device, tmp_path, monkeypatch):
+    from pccs_accel import scene
+    from pccs_accel.utils.data_process import gen_prob, get_scene_data, process_scene
+    g = load_golden("g12_scene_soft_labels")
+    trj = _g12_inputs(g)
+    marks = [int(v) for v in g["split_marks"]]
+    n, K = len(trj), int(g["K"])
+    offsets, ids = scene.scene_neighbors(trj, marks, int(g["obs_len"]), float(g["rad"]))
+    assert np.array_equal(offsets.cpu().numpy(), g["nb_off"]) and np.array_equal(ids.cpu().numpy(), g["nb_ids"])
+    dense = scene.soft_labels(offsets, ids, g["labels"], K)
+    assert np.array_equal(dense.cpu().numpy(), g["dense"])                  # counts / (len + 1): exact doubles
+    # the drop-ins, with the reference's files
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "processed_scene" / "ethucy" / "toy").mkdir(parents=True)
+    (tmp_path / "save").mkdir()
+    args = argparse.Namespace(obs_len=int(g["obs_len"]), pred_len=12, data_from="ethucy", rad=float(g["rad"]), n_cluster=K,
+                              no_time_check=True)
+    train_set = argparse.Namespace(trj_data=torch.from_numpy(trj).float(), split_marks=marks)
+    d = process_scene("toy", train_set, args)
+    assert all(d[i] == list(g["nb_ids"][g["nb_off"][i]:g["nb_off"][i + 1]]) for i in range(n))
+    import pickle
+    with open(tmp_path / "processed_scene" / "ethucy" / "toy" / "scene_1.0_8.pkl", "rb") as f:
+        assert pickle.load(f) == d
+    rc, rp = gen_prob(d, g["labels"], str(tmp_path / "save"))
+    assert np.array_equal(np.concatenate(rc), g["classes"]) and np.array_equal(np.concatenate(rp), g["probs"])
+    assert [len(c) for c in rc] == list(np.diff(g["cl_off"]))
+    for _ in range(2):  # second call: both caches hit
+        res = get_scene_data("toy", train_set, g["labels"], str(tmp_path / "save"), args)
+        assert res.dtype == np.float64 and np.array_equal(res, g["dense"])
+
+
+@pytest.mark.parametrize("sizes,rad", [([1], 1.0), ([2, 0, 3], 1.0), ([65, 64, 63], 0.5), ([1500], 0.75), ([400, 900], 2.0)])
+def test_scene_neighbours_shapes_vs_oracle(sizes, rad, gpu_device):
+    from pccs_accel import scene
+    parts = [datagen.make_scene_trajectories(500 + i + s, s, extent=5) for i, s in enumerate(sizes) if s]
+    trj = np.concatenate(parts)
+    marks = [0] + list(np.cumsum(sizes))
+    offsets, ids = scene.scene_neighbors(trj, marks, 8, rad)
+    want = G.process_scene(trj, marks, 8, rad)
+    off, flat = offsets.cpu().numpy(), ids.cpu().numpy()
+    got = {i: [int(v) for v in flat[off[i]:off[i + 1]]] for i in range(len(trj))}
+    if got != want:
+        assert _classify_neighbour_mismatches(trj, marks, 8, rad, got, want) == 0
+    assert all(got[i] == sorted(got[i]) and i not in got[i] for i in got)
+    labels = np.random.RandomState(len(trj)).randint(0, 37, size=len(trj)).astype(np.int32)
+    dense = scene.soft_labels(offsets, ids, labels, 37).cpu().numpy()
+    rc, rp = G.gen_prob(got, labels)
+    assert np.array_equal(dense, G.scene_soft_labels(rc, rp, 37))
+    assert np.allclose(dense.sum(axis=1), 1.0)
+    with pytest.raises(IndexError):
+        scene.soft_labels(offsets, ids, labels, 36 if labels.max() == 36 else int(labels.max()))
