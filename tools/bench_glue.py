@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Timing of the SURVEY.md 8(f) kernels (decode glue, NMS re-ranking, scene soft labels) at sizes
+that fill the GPU, each with its algorithmic bytes / pair tests and the CPU oracle timed on a
+bounded sample beside it.  Development measurement: one JSON object per kernel on stdout; the
+numbers go to DESIGN.md.  (bench.py stays the headline line.)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("modular-trajectory-prediction-toolkit_amd", "oracle", os.path.join("tests", "golden")):
+    sys.path.insert(0, os.path.join(ROOT, p))
+
+from pccs_accel import kernels as K  # noqa: E402
+from pccs_accel import scene  # noqa: E402
+
+
+def timed(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def emit(name, ms, **kw):
+    out = {"kernel": name, "ms": ms}
+    out.update(kw)
+    if "bytes" in kw:
+        out["GB/s"] = kw["bytes"] / (ms * 1e-3) / 1e9
+        out["frac_of_8TB/s"] = out["GB/s"] / 8000.0
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    import glue_oracle as G
+    import kmeans_oracle as O
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+
+    # ---- f3: decode + fused displacement scoring, BASELINE configs[4] shape ----
+    n, k, t = 1_000_000, 100, 12
+    disp = torch.randn(n, k, t, 2, generator=g, device=dev) * 0.1
+    gt = torch.cumsum(torch.randn(n, t, 2, generator=g, device=dev) * 0.3, dim=1).contiguous()
+    th = torch.rand(n, generator=g, device=dev) * 6.28 - 3.14
+    rot = torch.stack([torch.stack([torch.cos(th), -torch.sin(th)], -1), torch.stack([torch.sin(th), torch.cos(th)], -1)], 1).contiguous()
+    last = torch.randn(n, 2, generator=g, device=dev)
+    out = torch.empty_like(disp)
+    tensor_bytes = disp.numel() * 4.0
+    ms = timed(lambda: K.decode_trajectories(disp, rot, last, out=out))
+    ns = 2000
+    t0 = time.perf_counter()
+    G.decode_predictions(disp[:ns].cpu().numpy(), rot[:ns].cpu().numpy(), last[:ns].cpu().numpy())
+    cpu = (time.perf_counter() - t0) / (ns * k)
+    emit("k_decode_trajectories (prefix sum + rotate + last_obs)", ms, bytes=2 * tensor_bytes + n * 24.0,
+         traj_per_s=n * k / (ms * 1e-3), cpu_oracle_traj_per_s=1 / cpu, shape=[n, k, t, 2])
+    ms = timed(lambda: K.decode_trajectories(disp, out=out))
+    emit("k_decode_trajectories (transform_trajectory only)", ms, bytes=2 * tensor_bytes, traj_per_s=n * k / (ms * 1e-3))
+    ms = timed(lambda: K.best_of_k_disp(disp, gt, mode=0, want_per_agent=True))
+    emit("k_best_of_k<disp> (prefix sum fused into scoring)", ms, bytes=tensor_bytes + n * (t * 8.0 + 16.0),
+         traj_per_s=n * k / (ms * 1e-3))
+    ms2 = timed(lambda: K.best_of_k(K.decode_trajectories(disp, out=out), gt, mode=0))
+    emit("two-pass: decode then k_best_of_k", ms2, bytes=3 * tensor_bytes, traj_per_s=n * k / (ms2 * 1e-3))
+    del disp, out, rot, last, gt
+
+    # ---- f4: NMS re-ranking of stored sets [N, 200, 12, 2] ----
+    for dtype, n in ((torch.float64, 100_000), (torch.float32, 200_000)):
+        m, t, best_of = 200, 12, 20
+        es = 8 if dtype == torch.float64 else 4
+        modes = torch.cumsum(torch.randn(n, 9, t, 2, generator=g, device=dev) * 0.35, dim=2)
+        z = torch.randint(0, 9, (n, m), generator=g, device=dev)
+        pred = (modes[torch.arange(n, device=dev)[:, None], z] + torch.randn(n, m, t, 2, generator=g, device=dev) * 0.12).to(dtype).contiguous()
+        fut = (modes[:, 0] + torch.randn(n, t, 2, generator=g, device=dev) * 0.1).to(dtype).contiguous()
+        scores = (torch.randint(-480, 161, (n, m), generator=g, device=dev).float() / 8.0).contiguous()
+        del modes, z
+        res = {}
+
+        def run():
+            res["o"] = K.nms_rerank(pred, scores, m, best_of, 2, 0.3)
+        ms = timed(run)
+        order, n_sel = res["o"]
+        ns = 300
+        t0 = time.perf_counter()
+        wo, _, _ = G.nms_rerank(pred[:ns].cpu().numpy(), scores[:ns].cpu().numpy(), m, best_of, 2, 0.3)
+        cpu = (time.perf_counter() - t0) / ns
+        assert np.array_equal(order[:ns].cpu().numpy(), wo)
+        emit(f"k_nms_rerank<{'f64' if es == 8 else 'f32'}>", ms, bytes=n * m * (4.0 + 2 * es + 4.0),
+             sector_bytes=n * m * (4.0 + 64.0 + 4.0), agents_per_s=n / (ms * 1e-3), cpu_oracle_agents_per_s=1 / cpu,
+             mean_kept=float(n_sel.float().mean()), shape=[n, m, t, 2])
+        ms = timed(lambda: K.gather_candidates(pred, order), reps=5)
+        emit(f"k_gather_candidates<{'f64' if es == 8 else 'f32'}>", ms, bytes=2.0 * pred.numel() * es + order.numel() * 4.0)
+        ms = timed(lambda: K.best_of_k_reranked(pred, fut, order, mode=0, ade_div=1.0, best_of=best_of))
+        emit(f"k_best_of_k<reranked,{'f64' if es == 8 else 'f32'}> (first 20 of the new order)", ms,
+             bytes=n * (best_of * t * 2.0 * es + t * 2.0 * es + best_of * 4.0 + 16.0), traj_per_s=n * best_of / (ms * 1e-3))
+        del pred, fut, scores, order
+
+    # ---- f2: scene neighbours + soft labels at the eth split's scene sizes (flip-augmented) ----
+    import datagen
+    sizes = [2 * v for v in (1075, 14295, 10039, 621, 2356, 5910, 2488)]
+    trj = np.concatenate([datagen.make_scene_trajectories(900 + i, s, extent=30) for i, s in enumerate(sizes)])
+    marks = [0] + list(np.cumsum(sizes))
+    n = len(trj)
+    d_trj = torch.from_numpy(trj).to(dev)
+    res = {}
+
+    def run_sc():
+        res["csr"] = scene.scene_neighbors(d_trj, marks, 8, 1.0)
+    ms = timed(run_sc, reps=5, warm=1)
+    offsets, ids = res["csr"]
+    pairs = float(sum(s * s for s in sizes))
+    ns = 300
+    t0 = time.perf_counter()
+    sub = G.process_scene(trj[marks[1]:marks[2]][:4000], [0, 4000], 8, 1.0)
+    cpu_pairs = 4000.0 * 4000.0 / (time.perf_counter() - t0)
+    emit("scene_neighbors (speed/angle + count pass + fill pass)", ms, pair_tests=pairs, pair_tests_per_s=2 * pairs / (ms * 1e-3),
+         cpu_oracle_pair_tests_per_s=cpu_pairs, reference_note="reference: Python double loop, ~120 min (PCCSNet/README.md:102)",
+         n=n, nnz=int(ids.numel()), scenes=sizes)
+    labels = torch.randint(0, 200, (n,), generator=g, device=dev).to(torch.int32)
+    ms = timed(lambda: scene.soft_labels(offsets, ids, labels, 200))
+    emit("k_soft_labels (K=200)", ms, bytes=n * 200 * 8.0 + ids.numel() * 12.0 + n * 20.0)
+
+
+if __name__ == "__main__":
+    main()
