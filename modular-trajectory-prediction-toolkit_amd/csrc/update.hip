@@ -7,7 +7,7 @@
 //   k_mstep_flags     convergence decision (sklearn cluster/_kmeans.py:715-734)
 //   k_inertia         sklearn cluster/_k_means_common.pyx:94-124
 //   k_col_*           KMeans.fit preprocessing (mean / variance / centring)
-//   k_point_dist, k_argmax_pass, k_apply_relocation   empty-cluster relocation
+//   k_argmax_partial, k_argmax_final, k_apply_relocation   empty-cluster relocation
 //
 // Sums are accumulated in double (LDS ds_add_f64, then global_atomic_add_f64): the order of the
 // additions then changes the result only at the 1e-16 level, so centroids do not depend on the
@@ -419,42 +419,70 @@ extern "C" int mtp_row_sqnorm_f32(const float *A, int64_t n, int d, float *out, 
 // passes (descending distance, ties to the lowest index); a selected point's distance is then
 // set to -1 so that the next pass skips it.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_argmax_pass(float *dist, int64_t n, int pass, const float *__restrict__ X,
-                                                      int d, const int32_t *__restrict__ labels, int64_t idx_offset,
-                                                      float *far_val, int64_t *far_idx, int32_t *far_lab,
-                                                      float *far_rows) {
-    __shared__ float sv[16];
-    __shared__ long long si[16];
-    float bv = -2.f;
-    long long bi = -1;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float v = dist[i];
-        if (v > bv) {
-            bv = v;
-            bi = i;
-        }
+static __device__ __align__(256) float g_argmax_pval[1024];
+static __device__ __align__(256) long long g_argmax_pidx[1024];
+
+// (value, index) maximum, ties to the lowest index; index -1 = "nothing yet"
+__device__ __forceinline__ void argmax_merge(float &bv, long long &bi, float ov, long long oi) {
+    if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) {
+        bv = ov;
+        bi = oi;
     }
+}
+
+__device__ __forceinline__ void argmax_block(float &bv, long long &bi, float *sv, long long *si) {
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(bv, o);
         const long long oi = __shfl_xor(bi, o);
-        if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) {
-            bv = ov;
-            bi = oi;
-        }
+        argmax_merge(bv, bi, ov, oi);
     }
     if ((threadIdx.x & 63) == 0) {
         sv[threadIdx.x >> 6] = bv;
         si[threadIdx.x >> 6] = bi;
     }
     __syncthreads();
-    __shared__ long long win;
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
-            if (sv[w] > bv || (sv[w] == bv && si[w] >= 0 && (bi < 0 || si[w] < bi))) {
-                bv = sv[w];
-                bi = si[w];
-            }
+    if (threadIdx.x == 0)
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) argmax_merge(bv, bi, sv[w], si[w]);
+}
+
+// stage 1: every block scans a contiguous slice of dist (entries < 0 are already taken)
+__global__ __launch_bounds__(1024) void k_argmax_partial(const float *__restrict__ dist, int64_t n, int64_t per_block,
+                                                         float *pval, long long *pidx) {
+    __shared__ float sv[16];
+    __shared__ long long si[16];
+    const int64_t b = (int64_t)blockIdx.x * per_block, e = min(n, b + per_block);
+    float bv = -2.f;
+    long long bi = -1;
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        const float v = dist[i];
+        if (v >= 0.f && (bi < 0 || v > bv)) {  // ascending i per thread: the first maximum is kept
+            bv = v;
+            bi = i;
         }
+    }
+    argmax_block(bv, bi, sv, si);
+    if (threadIdx.x == 0) {
+        pval[blockIdx.x] = bv;
+        pidx[blockIdx.x] = bi;
+    }
+}
+
+// stage 2 (one block): winner of the partials -> far_*[pass]; its distance is set to -1 so that the
+// next pass skips it
+__global__ __launch_bounds__(1024) void k_argmax_final(float *dist, const float *__restrict__ pval,
+                                                       const long long *__restrict__ pidx, int n_part, int pass,
+                                                       const float *__restrict__ X, int d,
+                                                       const int32_t *__restrict__ labels, int64_t idx_offset,
+                                                       float *far_val, int64_t *far_idx, int32_t *far_lab,
+                                                       float *far_rows) {
+    __shared__ float sv[16];
+    __shared__ long long si[16];
+    __shared__ long long win;
+    float bv = -2.f;
+    long long bi = -1;
+    for (int q = threadIdx.x; q < n_part; q += blockDim.x) argmax_merge(bv, bi, pval[q], pidx[q]);
+    argmax_block(bv, bi, sv, si);
+    if (threadIdx.x == 0) {
         win = bi;
         far_val[pass] = bi >= 0 ? bv : -1.f;
         far_idx[pass] = bi >= 0 ? bi + idx_offset : -1;
@@ -474,9 +502,27 @@ extern "C" int mtp_far_points_f32(const float *X, int64_t n, int d, const float 
     hipStream_t s = mtp_stream(stream);
     int rc = mtp_launch_inertia(X, n, d, C_old, labels, nullptr, dist_scratch, s);
     if (rc != MTP_OK) return rc;
+    // m argmax passes, each a grid-wide scan (<= 1024 slices) + a one-block merge; the slice
+    // winners live in a file-scope device buffer (one far-point search per device at a time)
+    static float *pval[64] = {nullptr};
+    static long long *pidx[64] = {nullptr};
+    int dev = 0;
+    MTP_HIP(hipGetDevice(&dev));
+    MTP_REQUIRE(dev >= 0 && dev < 64, "mtp_far_points: device index out of range");
+    if (pval[dev] == nullptr) {
+        MTP_HIP(hipGetSymbolAddress(reinterpret_cast<void **>(&pval[dev]), HIP_SYMBOL(g_argmax_pval)));
+        MTP_HIP(hipGetSymbolAddress(reinterpret_cast<void **>(&pidx[dev]), HIP_SYMBOL(g_argmax_pidx)));
+    }
+    int n_part = (int)((n + 8191) / 8192);
+    if (n_part > 1024) n_part = 1024;
+    if (n_part < 1) n_part = 1;
+    const int64_t per_block = (n + n_part - 1) / n_part;
     for (int p = 0; p < m; ++p) {
-        hipLaunchKernelGGL(k_argmax_pass, dim3(1), dim3(1024), 0, s, dist_scratch, n, p, X, d, labels, idx_offset,
-                           far_val, far_idx, far_lab, far_rows);
+        hipLaunchKernelGGL(k_argmax_partial, dim3(n_part), dim3(1024), 0, s, dist_scratch, n, per_block, pval[dev],
+                           pidx[dev]);
+        MTP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(1024), 0, s, dist_scratch, pval[dev], pidx[dev], n_part, p, X, d,
+                           labels, idx_offset, far_val, far_idx, far_lab, far_rows);
         MTP_LAUNCH_CHECK();
     }
     return MTP_OK;
