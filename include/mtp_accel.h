@@ -158,6 +158,16 @@ int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int m
                   int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, void *ws,
                   size_t ws_bytes, void *stream);
 
+/* n_init restarts at once (the loop over inits of sklearn KMeans.fit, cluster/_kmeans.py:1495-1532, which
+ * PCCSNet/utils/utility.py:120-121 runs with n_init=20): `batch` independent mtp_lloyd_f32 runs on the same
+ * points sharing every launch, each with its own state / convergence.  d must be 64, 96 or 128.
+ *   C_inout [batch, k, d]; labels_out [batch, n]; inertia_out [batch] doubles (device);
+ *   n_iter_out [batch] ints (HOST);  ws: mtp_lloyd_batched_workspace_bytes(k, d, batch, n) bytes. */
+int64_t mtp_lloyd_batched_workspace_bytes(int k, int d, int batch, int64_t n);
+int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_inout, int k, int batch, int max_iter,
+                          double tol_abs, int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out,
+                          void *ws, size_t ws_bytes, void *stream);
+
 /* k-means++ seeding, sklearn cluster/_kmeans.py:174-272 with unit sample weights, for one
  * restart.  The caller draws the random numbers from the same NumPy RandomState in sklearn's
  * order -- center_id = rs.choice(n, p=w/w.sum()), then u = rs.uniform(size=(k-1, l)) with
@@ -167,6 +177,12 @@ int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int m
 int64_t mtp_kpp_workspace_bytes(int64_t n, int d, int l);
 int mtp_kmeans_plusplus_f32(const float *X, int64_t n, int d, int k, int l, int64_t center_id, const double *u,
                             int64_t *indices_out, float *centers_out, void *ws, size_t ws_bytes, void *stream);
+/* The same for `batch` restarts sharing every launch: center_ids [batch] int64 (DEVICE), u [batch, k-1, l],
+ * indices_out [batch, k], centers_out [batch, k, d]; ws: mtp_kpp_batched_workspace_bytes(n, d, l, batch). */
+int64_t mtp_kpp_batched_workspace_bytes(int64_t n, int d, int l, int batch);
+int mtp_kmeans_plusplus_batched_f32(const float *X, int64_t n, int d, int k, int l, int batch, const int64_t *center_ids,
+                                    const double *u, int64_t *indices_out, float *centers_out, void *ws,
+                                    size_t ws_bytes, void *stream);
 
 /* Best-of-K ADE/FDE.  pred [n, kstride, t, 2], gt [n, t, 2]; the first k (<= kstride)
  * candidates of every agent are scored:

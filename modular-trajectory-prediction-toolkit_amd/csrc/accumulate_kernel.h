@@ -15,9 +15,16 @@ template <int LPR, int G, typename ACC, bool DO_ADD>
 __global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X, int64_t n, int d,
                                                      const int32_t *__restrict__ labels, int k, int kr,
                                                      int64_t rows_per_chunk, double *sums, double *counts,
-                                                     const int32_t *state) {
+                                                     const int32_t *state, MtpBatchStride bs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];  // kr*d ACC, then kr ints
     ACC *acc = reinterpret_cast<ACC *>(acc_raw);
+    {
+        const size_t b = blockIdx.z;  // restart
+        labels += b * bs.labels;
+        sums += b * bs.red;
+        counts += b * bs.red;
+        if (state != nullptr) state += b * bs.flags;
+    }
     if (state != nullptr && *state != MTP_STATE_RUNNING) return;
     const int k0 = blockIdx.y * kr;
     const int kn = min(kr, k - k0);

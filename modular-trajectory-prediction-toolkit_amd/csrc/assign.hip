@@ -69,7 +69,14 @@ __global__ __launch_bounds__(256) void k_assign_generic(const float *__restrict_
 
 // Stage C [k, d] -> staged image + c2 (einsum order).  One block per (padded) centroid row.
 __global__ __launch_bounds__(64) void k_stage_centers(const float *__restrict__ C, int k, int d, float *staged,
-                                                      float *c2, const int32_t *state) {
+                                                      float *c2, const int32_t *state, MtpBatchStride bs) {
+    {
+        const size_t b = blockIdx.y;
+        C += b * bs.c0;
+        if (staged != nullptr) staged += b * bs.staged;
+        if (c2 != nullptr) c2 += b * bs.kvec;
+        if (state != nullptr) state += b * bs.flags;
+    }
     if (state != nullptr && *state != MTP_STATE_RUNNING) return;
     const int j = blockIdx.x;
     const bool valid = j < k;
@@ -83,17 +90,18 @@ __global__ __launch_bounds__(64) void k_stage_centers(const float *__restrict__ 
 }
 
 int mtp_launch_stage_centers(const float *C, int k, int d, float *staged, float *c2, const int32_t *state,
-                             hipStream_t s) {
+                             hipStream_t s, MtpBatchStride bs) {
     const bool mfma = mtp_mfma_dim(d);
     const int rows = mfma ? mtp_n_tiles(k) * 32 : k;
-    hipLaunchKernelGGL(k_stage_centers, dim3(rows), dim3(64), 0, s, C, k, d, mfma ? staged : nullptr, c2, state);
+    hipLaunchKernelGGL(k_stage_centers, dim3(rows, bs.batch), dim3(64), 0, s, C, k, d, mfma ? staged : nullptr, c2,
+                       state, bs);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
 
 template <int D>
 static int launch_assign_mfma(const float *X, int64_t n, const float *staged, int k, int32_t *labels,
-                              double *n_changed, const int32_t *state, hipStream_t s) {
+                              double *n_changed, const int32_t *state, hipStream_t s, MtpBatchStride bs) {
     // 8 waves x 32 points per workgroup, 2 workgroups (4 waves/SIMD) per CU: measured 4 % faster
     // than 4 waves x 64 points at 2 waves/SIMD (tools/assign_tune.hip, N=10M K=1024 D=128)
     constexpr int PT = 1, CTW = 2, WPB = 8, WPS = 4;
@@ -107,21 +115,22 @@ static int launch_assign_mfma(const float *X, int64_t n, const float *staged, in
     const int64_t pts_per_block = WPB * 32 * PT;
     const int64_t blocks = (n + pts_per_block - 1) / pts_per_block;
     MTP_REQUIRE(blocks <= 0x7fffffff, "mtp_assign: n too large");
-    hipLaunchKernelGGL((k_assign_mfma<D, PT, CTW, WPB, WPS, true>), dim3((unsigned)blocks), dim3(64 * WPB), lds, s, X, n, staged, mtp_n_tiles(k),
-                       labels, n_changed, state);
+    hipLaunchKernelGGL((k_assign_mfma<D, PT, CTW, WPB, WPS, true>), dim3((unsigned)blocks, bs.batch), dim3(64 * WPB), lds, s, X, n,
+                       staged, mtp_n_tiles(k), labels, n_changed, state, bs);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
 
 int mtp_launch_assign(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2, int k,
-                      int32_t *labels, double *n_changed, const int32_t *state, hipStream_t s) {
+                      int32_t *labels, double *n_changed, const int32_t *state, hipStream_t s, MtpBatchStride bs) {
     if (n == 0) return MTP_OK;
+    MTP_REQUIRE(bs.batch == 1 || mtp_mfma_dim(d), "mtp_assign: batched restarts need d in {64, 96, 128} (got %d)", d);
     if (mtp_mfma_dim(d)) {
         MTP_REQUIRE(staged != nullptr, "mtp_assign: staged centroid image missing for d=%d", d);
         switch (d) {
-            case 64: return launch_assign_mfma<64>(X, n, staged, k, labels, n_changed, state, s);
-            case 96: return launch_assign_mfma<96>(X, n, staged, k, labels, n_changed, state, s);
-            case 128: return launch_assign_mfma<128>(X, n, staged, k, labels, n_changed, state, s);
+            case 64: return launch_assign_mfma<64>(X, n, staged, k, labels, n_changed, state, s, bs);
+            case 96: return launch_assign_mfma<96>(X, n, staged, k, labels, n_changed, state, s, bs);
+            case 128: return launch_assign_mfma<128>(X, n, staged, k, labels, n_changed, state, s, bs);
         }
     }
     MTP_REQUIRE(d >= 1 && d <= 1024, "mtp_assign: generic kernel supports 1 <= d <= 1024 (got %d)", d);

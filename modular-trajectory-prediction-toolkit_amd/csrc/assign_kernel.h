@@ -45,14 +45,22 @@ template <int D, int PT, int CTW, int WPB, int WPS, bool EPI, int LG = 8, bool P
 __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__restrict__ X, int64_t n,
                                                         const float *__restrict__ staged, int n_tiles,
                                                         int32_t *__restrict__ labels, double *n_changed,
-                                                        const int32_t *state) {
+                                                        const int32_t *state, MtpBatchStride bs) {
     constexpr int R = D / 4;                 // 16-byte slots per centroid row
     constexpr int TILE_F = 32 * (D + 4) + 32;  // floats per 32-centroid tile image (rows padded by one slot)
     constexpr int STAGE_F = CTW * TILE_F;
     constexpr int STAGE_SLOTS = STAGE_F / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * STAGE_F floats
 
-    if (state != nullptr && *state != MTP_STATE_RUNNING) return;
+    // restarts batched along blockIdx.y: every restart has its own centroid image, labels and loop state
+    {
+        const size_t b = blockIdx.y;
+        staged += b * bs.staged;
+        labels += b * bs.labels;
+        if (n_changed != nullptr) n_changed += b * bs.red;
+        if (state != nullptr) state += b * bs.flags;
+    }
+    if (mtp_skip(state, bs.skip_mode)) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;

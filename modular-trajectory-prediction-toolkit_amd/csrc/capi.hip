@@ -1,5 +1,6 @@
 // C-ABI entry points of libmtp_accel.so (see include/mtp_accel.h) and the single-GPU Lloyd driver.
 #include <cstring>
+#include <vector>
 
 #include "mtp_internal.h"
 
@@ -221,6 +222,123 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
         if (rc != MTP_OK) return rc;
     }
     if (n_iter_out != nullptr) *n_iter_out = n_iter;
+    MTP_HIP(hipStreamSynchronize(s));
+    return MTP_OK;
+}
+
+// ---- n_init restarts at once: sklearn KMeans.fit's loop over inits (cluster/_kmeans.py:1495-1532) ----
+// Every restart runs _kmeans_single_lloyd on the same points from its own initial centres; the
+// restarts share each launch (blockIdx.y / .z = restart), keep their own loop state and stop
+// on their own.  At reference scale (N ~ 7e4, K = 200) one restart cannot fill the GPU and an
+// iteration is launch-bound; 20 restarts per launch are what makes the fit fast.
+extern "C" int64_t mtp_lloyd_batched_workspace_bytes(int k, int d, int batch, int64_t n) {
+    if (k <= 0 || d <= 0 || batch <= 0 || n < 0) return 0;
+    return (int64_t)(carve_lloyd(nullptr, k, d).bytes * (size_t)batch + align_up((size_t)n * 4, 256));
+}
+
+extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_inout, int k, int batch, int max_iter,
+                                     double tol_abs, int check_every, int32_t *labels_out, double *inertia_out,
+                                     int *n_iter_out, void *ws, size_t ws_bytes, void *stream) {
+    MTP_REQUIRE(X && C_inout && labels_out && ws, "mtp_lloyd_batched: null pointer");
+    MTP_REQUIRE(n >= k && k >= 1 && d >= 1 && max_iter >= 1, "mtp_lloyd_batched: bad shape n=%lld k=%d d=%d max_iter=%d",
+                (long long)n, k, d, max_iter);
+    MTP_REQUIRE(batch >= 1 && batch <= 1024, "mtp_lloyd_batched: batch must be in [1, 1024] (got %d)", batch);
+    MTP_REQUIRE(mtp_mfma_dim(d), "mtp_lloyd_batched: d must be 64, 96 or 128 (got %d); run the restarts one by one", d);
+    const LloydWs w = carve_lloyd(ws, k, d);  // restart 0; restart b sits b * w.bytes further
+    const size_t need = (size_t)mtp_lloyd_batched_workspace_bytes(k, d, batch, n);
+    if (ws_bytes < need) {
+        mtp_set_error("mtp_lloyd_batched: workspace of %zu bytes, need %zu", ws_bytes, need);
+        return MTP_E_WORKSPACE;
+    }
+    float *dist_scratch = reinterpret_cast<float *>(static_cast<char *>(ws) + w.bytes * (size_t)batch);
+    hipStream_t s = mtp_stream(stream);
+    if (check_every < 1) check_every = 1;
+    MtpBatchStride bs;
+    bs.staged = w.bytes / 4;
+    bs.labels = (size_t)n;
+    bs.red = w.bytes / 8;
+    bs.flags = w.bytes / 4;
+    bs.c0 = (size_t)k * d;
+    bs.c1 = w.bytes / 4;
+    bs.kvec = w.bytes / 4;
+    bs.skip_mode = 0;
+    bs.batch = batch;
+    auto at = [&](auto *p, int b) { return reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + w.bytes * (size_t)b); };
+
+    // begin: zero red + flags of every restart, stage the initial centres, labels_old = -1
+    MTP_HIP(hipMemset2DAsync(w.red, w.bytes, 0, (size_t)mtp_red_len(k, d) * 8, batch, s));
+    MTP_HIP(hipMemset2DAsync(w.flags, w.bytes, 0, MTP_FLAG_WORDS * 4, batch, s));
+    int rc = mtp_launch_stage_centers(C_inout, k, d, w.staged, w.c2, nullptr, s, bs);
+    if (rc != MTP_OK) return rc;
+    MTP_HIP(hipMemsetAsync(labels_out, 0xff, (size_t)n * 4 * batch, s));
+
+    std::vector<int32_t> hflags((size_t)batch * MTP_FLAG_WORDS);
+    auto read_flags = [&]() -> int {
+        MTP_HIP(hipMemcpy2DAsync(hflags.data(), MTP_FLAG_WORDS * 4, w.flags, w.bytes, MTP_FLAG_WORDS * 4, batch,
+                                 hipMemcpyDeviceToHost, s));
+        MTP_HIP(hipStreamSynchronize(s));
+        return MTP_OK;
+    };
+    const int max_rounds = 2 * (max_iter / check_every + 1) + 2 * max_iter + 8;
+    for (int round = 0;; ++round) {
+        MTP_REQUIRE(round < max_rounds, "mtp_lloyd_batched: the restarts did not finish (internal error)");
+        for (int i = 0; i < check_every; ++i) {
+            // centres of a restart: buffer (n_iter & 1); the MFMA E-step only reads the staged image
+            rc = mtp_launch_assign(X, n, d, nullptr, w.staged, w.c2, k, labels_out, w.red + (size_t)k * d + k, w.flags, s, bs);
+            if (rc != MTP_OK) return rc;
+            rc = mtp_launch_accumulate(X, n, d, labels_out, k, w.red, w.red + (size_t)k * d, w.flags, s, bs);
+            if (rc != MTP_OK) return rc;
+            rc = mtp_launch_mstep(w.red, C_inout, w.c_alt, k, d, tol_abs, max_iter, 0, w.staged, w.c2, w.shift, w.flags,
+                                  nullptr, s, bs, 1);
+            if (rc != MTP_OK) return rc;
+        }
+        rc = read_flags();
+        if (rc != MTP_OK) return rc;
+        bool any_live = false;
+        for (int b = 0; b < batch; ++b) {
+            const int32_t *f = &hflags[(size_t)b * MTP_FLAG_WORDS];
+            if (f[MTP_FLAG_STATE] == MTP_STATE_RELOCATE) {
+                // this restart paused before its M-step: relocate, then redo its M-step alone
+                const int old = f[MTP_FLAG_N_ITER] & 1;
+                int m = f[MTP_FLAG_N_EMPTY];
+                if (m > MTP_MAX_RELOC) m = MTP_MAX_RELOC;
+                float *c0 = C_inout + (size_t)b * k * d, *c1 = at(w.c_alt, b);
+                rc = mtp_far_points_f32(X, n, d, old ? c1 : c0, labels_out + (size_t)b * n, m, 0, at(w.far_val, b),
+                                        at(w.far_idx, b), at(w.far_lab, b), at(w.far_rows, b), dist_scratch, stream);
+                if (rc != MTP_OK) return rc;
+                rc = mtp_apply_relocation_f32(at(w.red, b), k, d, m, at(w.far_val, b), at(w.far_lab, b), at(w.far_rows, b),
+                                              stream);
+                if (rc != MTP_OK) return rc;
+                MTP_HIP(hipMemsetAsync(at(w.flags, b) + MTP_FLAG_STATE, 0, 4, s));
+                MtpBatchStride one = bs;
+                one.batch = 1;
+                rc = mtp_launch_mstep(at(w.red, b), c0, c1, k, d, tol_abs, max_iter, 1, at(w.staged, b), at(w.c2, b),
+                                      at(w.shift, b), at(w.flags, b), nullptr, s, one, 1);
+                if (rc != MTP_OK) return rc;
+                any_live = true;
+            } else if (f[MTP_FLAG_STATE] == MTP_STATE_RUNNING) {
+                any_live = true;
+            }
+        }
+        if (!any_live) break;
+    }
+    // labels must match the final centres: one more E-step for every restart that did not stop on
+    // "labels unchanged" (_kmeans.py:736-748); staged already describes the final centres
+    MtpBatchStride fin = bs;
+    fin.skip_mode = 1;
+    rc = mtp_launch_assign(X, n, d, nullptr, w.staged, w.c2, k, labels_out, nullptr, w.flags, s, fin);
+    if (rc != MTP_OK) return rc;
+    if (inertia_out != nullptr) MTP_HIP(hipMemsetAsync(inertia_out, 0, 8 * (size_t)batch, s));
+    for (int b = 0; b < batch; ++b) {
+        const int n_iter = hflags[(size_t)b * MTP_FLAG_WORDS + MTP_FLAG_N_ITER];
+        float *c0 = C_inout + (size_t)b * k * d;
+        if (n_iter & 1) MTP_HIP(hipMemcpyAsync(c0, at(w.c_alt, b), (size_t)k * d * 4, hipMemcpyDeviceToDevice, s));
+        if (inertia_out != nullptr) {
+            rc = mtp_launch_inertia(X, n, d, c0, labels_out + (size_t)b * n, inertia_out + b, nullptr, s);
+            if (rc != MTP_OK) return rc;
+        }
+        if (n_iter_out != nullptr) n_iter_out[b] = n_iter;
+    }
     MTP_HIP(hipStreamSynchronize(s));
     return MTP_OK;
 }

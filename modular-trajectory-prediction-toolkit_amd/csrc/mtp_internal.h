@@ -49,18 +49,42 @@ __host__ __device__ inline int mtp_n_tiles(int k) { return ((k + 32 * MTP_TILE_P
 // The sklearn Lloyd "red" buffer layout: sums[k*d], counts[k], n_changed, spare
 __host__ __device__ inline int64_t mtp_red_len(int k, int d) { return (int64_t)k * d + k + 2; }
 
+// Restart batching (blockIdx.y / .z = restart b): element strides from one restart's buffer to the
+// next; all zero for a single run.  skip_mode 0: a kernel runs only while the restart's state is
+// RUNNING; 1: it runs unless the state is STRICT (the final E-step of sklearn _kmeans.py:736-748).
+struct MtpBatchStride {
+    size_t staged;  // floats
+    size_t labels;  // int32s
+    size_t red;     // doubles
+    size_t flags;   // int32s
+    size_t c0, c1;  // floats: the two centre ping-pong buffers
+    size_t kvec;    // floats: c2 / shift arrays
+    int skip_mode;
+    int batch;
+};
+static inline MtpBatchStride mtp_no_batch() { return MtpBatchStride{0, 0, 0, 0, 0, 0, 0, 0, 1}; }
+
+__device__ __forceinline__ bool mtp_skip(const int32_t *state, int skip_mode) {
+    if (state == nullptr) return false;
+    const int st = *state;
+    return skip_mode == 0 ? st != MTP_STATE_RUNNING : st == MTP_STATE_STRICT;
+}
+
 static inline hipStream_t mtp_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- launchers implemented across the .hip files (all enqueue only) ----
 int mtp_launch_stage_centers(const float *C, int k, int d, float *staged, float *c2, const int32_t *state,
-                             hipStream_t s);
+                             hipStream_t s, MtpBatchStride bs = mtp_no_batch());
 int mtp_launch_assign(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2, int k,
-                      int32_t *labels, double *n_changed, const int32_t *state, hipStream_t s);
+                      int32_t *labels, double *n_changed, const int32_t *state, hipStream_t s,
+                      MtpBatchStride bs = mtp_no_batch());
 int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,
-                          double *counts, const int32_t *state, hipStream_t s);
+                          double *counts, const int32_t *state, hipStream_t s, MtpBatchStride bs = mtp_no_batch());
+// flag_parity = 0: C_old / C_new as given.  1 (batched runs): C_old is buffer 0 of the restart, C_new
+// buffer 1, swapped when the restart's n_iter is odd -- restarts drift apart when one of them pauses.
 int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
                      int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, double *red_backup,
-                     hipStream_t s);
+                     hipStream_t s, MtpBatchStride bs = mtp_no_batch(), int flag_parity = 0);
 int mtp_launch_inertia(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
                        float *per_point, hipStream_t s);
 

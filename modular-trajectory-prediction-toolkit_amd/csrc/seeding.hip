@@ -21,8 +21,19 @@ static constexpr int KPP_PB = 256;     // points per block of k_kpp_dist (one pe
 static constexpr int KPP_Q = KPP_PB / 64;  // points per lane in the in-block scan
 static constexpr int KPP_MAX_L = 16;   // local trials: 2 + int(ln K) <= 16 up to K ~ 1.2e6
 
+// Restarts are batched along blockIdx.y: restart b uses the pointers below moved by b * stride
+// bytes (yy is shared: it only depends on X).
+template <typename T>
+__host__ __device__ __forceinline__ T *kpp_at(T *p, size_t stride, int b) {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(p) + stride * (size_t)b);
+}
+template <typename T>
+__host__ __device__ __forceinline__ const T *kpp_at(const T *p, size_t stride, int b) {
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(p) + stride * (size_t)b);
+}
+
 struct KppWs {
-    double *yy;        // [n]  |y|^2 of the upcast rows
+    double *yy;        // [n]  |y|^2 of the upcast rows (shared by all restarts)
     float *rows;       // [2][L][n] closest-distance rows (ping-pong over steps)
     double *bsum;      // [2][L][nblk] per-block sums of those rows
     double *prefix;    // [nblk] scratch: inclusive prefix of the selected row's block sums
@@ -31,12 +42,13 @@ struct KppWs {
     int64_t *cand;     // [L] candidate ids
     int32_t *state;    // [0] = selected candidate of the current rows
     float *pot;        // [1] current potential (float32 like sklearn's)
-    size_t bytes;
+    size_t stride;     // bytes from one restart's block to the next
+    size_t bytes;      // total for `batch` restarts
 };
 
 static inline size_t kpp_align(size_t v) { return (v + 255) / 256 * 256; }
 
-static KppWs kpp_carve(void *ws, int64_t n, int d, int l) {
+static KppWs kpp_carve(void *ws, int64_t n, int d, int l, int batch) {
     KppWs w;
     const int64_t nblk = (n + KPP_PB - 1) / KPP_PB;
     size_t off = 0;
@@ -46,6 +58,7 @@ static KppWs kpp_carve(void *ws, int64_t n, int d, int l) {
         return p;
     };
     w.yy = static_cast<double *>(take((size_t)n * 8));
+    const size_t first = off;
     w.rows = static_cast<float *>(take((size_t)2 * l * n * 4));
     w.bsum = static_cast<double *>(take((size_t)2 * l * nblk * 8));
     w.prefix = static_cast<double *>(take((size_t)nblk * 8));
@@ -54,13 +67,18 @@ static KppWs kpp_carve(void *ws, int64_t n, int d, int l) {
     w.cand = static_cast<int64_t *>(take((size_t)l * 8));
     w.state = static_cast<int32_t *>(take(64));
     w.pot = static_cast<float *>(take(64));
-    w.bytes = off;
+    w.stride = off - first;
+    w.bytes = first + w.stride * (size_t)batch;
     return w;
 }
 
 extern "C" int64_t mtp_kpp_workspace_bytes(int64_t n, int d, int l) {
     if (n <= 0 || d <= 0 || l <= 0 || l > KPP_MAX_L) return 0;
-    return (int64_t)kpp_carve(nullptr, n, d, l).bytes;
+    return (int64_t)kpp_carve(nullptr, n, d, l, 1).bytes;
+}
+extern "C" int64_t mtp_kpp_batched_workspace_bytes(int64_t n, int d, int l, int batch) {
+    if (n <= 0 || d <= 0 || l <= 0 || l > KPP_MAX_L || batch <= 0) return 0;
+    return (int64_t)kpp_carve(nullptr, n, d, l, batch).bytes;
 }
 
 // |y|^2 per row in double
@@ -82,9 +100,18 @@ __global__ __launch_bounds__(256) void k_kpp_dist(const float *__restrict__ X, i
                                                   const double *__restrict__ cand_xx, const double *__restrict__ yy,
                                                   const float *rows_prev /* [L][n] */, const int32_t *sel_prev,
                                                   int has_prev, float *rows_out /* [L][n] */, double *bsum_out,
-                                                  int64_t nblk) {
+                                                  int64_t nblk, size_t bstride) {
     extern __shared__ __attribute__((aligned(16))) double sx[];  // LT * d candidate rows (zero padded)
     __shared__ double part[LT][4];
+    {
+        const int b = blockIdx.y;
+        cand_x = kpp_at(cand_x, bstride, b);
+        cand_xx = kpp_at(cand_xx, bstride, b);
+        rows_prev = kpp_at(rows_prev, bstride, b);
+        sel_prev = kpp_at(sel_prev, bstride, b);
+        rows_out = kpp_at(rows_out, bstride, b);
+        bsum_out = kpp_at(bsum_out, bstride, b);
+    }
     for (int e = threadIdx.x; e < LT * d; e += 256) sx[e] = e < n_cand * d ? cand_x[e] : 0.0;
     __syncthreads();
     const float *prev = has_prev ? rows_prev + (size_t)(*sel_prev) * n : nullptr;
@@ -135,17 +162,17 @@ __global__ __launch_bounds__(256) void k_kpp_dist(const float *__restrict__ X, i
 }
 
 static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const KppWs &w, const float *rows_prev,
-                           int has_prev, float *rows_out, double *bsum_out, int64_t nblk, hipStream_t s) {
-    const dim3 grid((unsigned)nblk), block(256);
+                           int has_prev, float *rows_out, double *bsum_out, int64_t nblk, int batch, hipStream_t s) {
+    const dim3 grid((unsigned)nblk, (unsigned)batch), block(256);
     if (n_cand == 1)
         hipLaunchKernelGGL(k_kpp_dist<1>, grid, block, (size_t)1 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy,
-                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk);
+                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride);
     else if (n_cand <= 8)
         hipLaunchKernelGGL(k_kpp_dist<8>, grid, block, (size_t)8 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy,
-                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk);
+                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride);
     else
         hipLaunchKernelGGL(k_kpp_dist<16>, grid, block, (size_t)16 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx,
-                           w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out, nblk);
+                           w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
@@ -157,7 +184,22 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
                                                      int n_new, const double *__restrict__ u /* [n_new] */,
                                                      const float *rows_cur, const double *bsum_cur, int64_t nblk,
                                                      double *prefix, int64_t *cand, double *cand_x, double *cand_xx,
-                                                     int32_t *state, float *pot_out, int64_t *index_out) {
+                                                     int32_t *state, float *pot_out, int64_t *index_out,
+                                                     size_t bstride, size_t u_stride /* doubles */,
+                                                     size_t index_stride /* int64s */) {
+    {
+        const int b = blockIdx.x;
+        if (u != nullptr) u += u_stride * b;
+        rows_cur = kpp_at(rows_cur, bstride, b);
+        bsum_cur = kpp_at(bsum_cur, bstride, b);
+        prefix = kpp_at(prefix, bstride, b);
+        cand = kpp_at(cand, bstride, b);
+        cand_x = kpp_at(cand_x, bstride, b);
+        cand_xx = kpp_at(cand_xx, bstride, b);
+        state = kpp_at(state, bstride, b);
+        pot_out = kpp_at(pot_out, bstride, b);
+        index_out += index_stride * b;
+    }
     __shared__ double red[16];
     __shared__ float pots[KPP_MAX_L];
     __shared__ int s_sel;
@@ -277,9 +319,14 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
     }
 }
 
-__global__ __launch_bounds__(64) void k_kpp_first(const float *__restrict__ X, int d, int64_t center_id, int64_t *cand,
-                                                  double *cand_x, double *cand_xx) {
+__global__ __launch_bounds__(64) void k_kpp_first(const float *__restrict__ X, int d, int64_t center_id,
+                                                  const int64_t *center_ids, int64_t *cand, double *cand_x,
+                                                  double *cand_xx, size_t bstride) {
     const int lane = threadIdx.x;
+    if (center_ids != nullptr) center_id = center_ids[blockIdx.x];
+    cand = kpp_at(cand, bstride, blockIdx.x);
+    cand_x = kpp_at(cand_x, bstride, blockIdx.x);
+    cand_xx = kpp_at(cand_xx, bstride, blockIdx.x);
     const float *x = X + center_id * d;
     double xx = 0.0;
     for (int k = lane; k < d; k += 64) {
@@ -296,21 +343,25 @@ __global__ __launch_bounds__(64) void k_kpp_first(const float *__restrict__ X, i
 
 __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X, int d, const int64_t *idx, int k,
                                                      float *out) {
+    idx += (size_t)blockIdx.y * k;
+    out += (size_t)blockIdx.y * k * d;
     const int j = blockIdx.x;
     const float *x = X + idx[j] * d;
     for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)j * d + c] = x[c];
 }
 
-extern "C" int mtp_kmeans_plusplus_f32(const float *X, int64_t n, int d, int k, int l, int64_t center_id,
-                                       const double *u, int64_t *indices_out, float *centers_out, void *ws,
-                                       size_t ws_bytes, void *stream) {
+static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, int64_t center_id,
+                   const int64_t *center_ids_dev, const double *u, int64_t *indices_out, float *centers_out, void *ws,
+                   size_t ws_bytes, void *stream) {
     MTP_REQUIRE(X && indices_out && centers_out && ws, "mtp_kmeans_plusplus: null pointer");
     MTP_REQUIRE(n >= 1 && d >= 1 && k >= 1 && k <= n, "mtp_kmeans_plusplus: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
+    MTP_REQUIRE(batch >= 1 && batch <= 65535, "mtp_kmeans_plusplus: batch must be in [1, 65535] (got %d)", batch);
     MTP_REQUIRE(l >= 1 && l <= KPP_MAX_L, "mtp_kmeans_plusplus: n_local_trials must be in [1, %d] (got %d)", KPP_MAX_L, l);
-    MTP_REQUIRE(center_id >= 0 && center_id < n, "mtp_kmeans_plusplus: first centre index out of range");
+    MTP_REQUIRE(center_ids_dev != nullptr || (center_id >= 0 && center_id < n),
+                "mtp_kmeans_plusplus: first centre index out of range");
     MTP_REQUIRE(k == 1 || u != nullptr, "mtp_kmeans_plusplus: uniform draws missing");
     MTP_REQUIRE((size_t)(l <= 8 ? 8 : 16) * d * 8 <= 60 * 1024, "mtp_kmeans_plusplus: d too large for the candidate tile");
-    KppWs w = kpp_carve(ws, n, d, l);
+    KppWs w = kpp_carve(ws, n, d, l, batch);
     if (ws_bytes < w.bytes) {
         mtp_set_error("mtp_kmeans_plusplus: workspace of %zu bytes, need %zu", ws_bytes, w.bytes);
         return MTP_E_WORKSPACE;
@@ -320,30 +371,45 @@ extern "C" int mtp_kmeans_plusplus_f32(const float *X, int64_t n, int d, int k, 
     MTP_REQUIRE(nblk <= 0x7fffffff, "mtp_kmeans_plusplus: n too large");
     hipLaunchKernelGGL(k_kpp_rownorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, n, d, w.yy);
     MTP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_kpp_first, dim3(1), dim3(64), 0, s, X, d, center_id, w.cand, w.cand_x, w.cand_xx);
+    hipLaunchKernelGGL(k_kpp_first, dim3(batch), dim3(64), 0, s, X, d, center_id, center_ids_dev, w.cand, w.cand_x,
+                       w.cand_xx, w.stride);
     MTP_LAUNCH_CHECK();
     // closest distances to the first centre: one "candidate", no previous row
-    int rc = launch_kpp_dist(X, n, d, 1, w, nullptr, 0, w.rows, w.bsum, nblk, s);
+    int rc = launch_kpp_dist(X, n, d, 1, w, nullptr, 0, w.rows, w.bsum, nblk, batch, s);
     if (rc != MTP_OK) return rc;
     int cur = 0, n_prev = 1;
+    const size_t u_stride = (size_t)(k - 1) * l;
     for (int c = 1; c <= k; ++c) {
         // select among the previous candidates -> centre c-1; draw the candidates for centre c
         const int n_new = c < k ? l : 0;
         float *rows_cur = w.rows + (size_t)cur * l * n;
         double *bsum_cur = w.bsum + (size_t)cur * l * nblk;
-        hipLaunchKernelGGL(k_kpp_select, dim3(1), dim3(1024), 0, s, X, n, d, n_prev, n_new,
+        hipLaunchKernelGGL(k_kpp_select, dim3(batch), dim3(1024), 0, s, X, n, d, n_prev, n_new,
                            c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
-                           w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1));
+                           w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1), w.stride, u_stride, (size_t)k);
         MTP_LAUNCH_CHECK();
         if (c == k) break;
         float *rows_nxt = w.rows + (size_t)(cur ^ 1) * l * n;
         double *bsum_nxt = w.bsum + (size_t)(cur ^ 1) * l * nblk;
-        rc = launch_kpp_dist(X, n, d, l, w, rows_cur, 1, rows_nxt, bsum_nxt, nblk, s);
+        rc = launch_kpp_dist(X, n, d, l, w, rows_cur, 1, rows_nxt, bsum_nxt, nblk, batch, s);
         if (rc != MTP_OK) return rc;
         cur ^= 1;
         n_prev = l;
     }
-    hipLaunchKernelGGL(k_gather_rows, dim3(k), dim3(128), 0, s, X, d, indices_out, k, centers_out);
+    hipLaunchKernelGGL(k_gather_rows, dim3(k, batch), dim3(128), 0, s, X, d, indices_out, k, centers_out);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
+}
+
+extern "C" int mtp_kmeans_plusplus_f32(const float *X, int64_t n, int d, int k, int l, int64_t center_id,
+                                       const double *u, int64_t *indices_out, float *centers_out, void *ws,
+                                       size_t ws_bytes, void *stream) {
+    return kpp_run(X, n, d, k, l, 1, center_id, nullptr, u, indices_out, centers_out, ws, ws_bytes, stream);
+}
+
+extern "C" int mtp_kmeans_plusplus_batched_f32(const float *X, int64_t n, int d, int k, int l, int batch,
+                                               const int64_t *center_ids, const double *u, int64_t *indices_out,
+                                               float *centers_out, void *ws, size_t ws_bytes, void *stream) {
+    MTP_REQUIRE(center_ids != nullptr, "mtp_kmeans_plusplus_batched: center_ids is NULL");
+    return kpp_run(X, n, d, k, l, batch, 0, center_ids, u, indices_out, centers_out, ws, ws_bytes, stream);
 }

@@ -30,9 +30,10 @@ __global__ __launch_bounds__(256) void k_accumulate_scalar(const float *__restri
 static constexpr size_t ACC_LDS_BYTES = 152 * 1024;
 
 int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,
-                          double *counts, const int32_t *state, hipStream_t s) {
+                          double *counts, const int32_t *state, hipStream_t s, MtpBatchStride bs) {
     if (n == 0) return MTP_OK;
     if (d % 4 != 0 || (size_t)d * 8 + 4 > ACC_LDS_BYTES) {
+        MTP_REQUIRE(bs.batch == 1, "mtp_centroid_sums: batched restarts need d %% 4 == 0");
         const int64_t blocks = (n + 255) / 256;
         MTP_REQUIRE(blocks <= 0x7fffffff, "mtp_centroid_sums: n too large");
         hipLaunchKernelGGL(k_accumulate_scalar, dim3((unsigned)blocks), dim3(256), 0, s, X, n, d, labels, k, sums,
@@ -48,13 +49,14 @@ int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *label
     const size_t lds = (size_t)kr * d * 8 + (size_t)kr * 4;
     // one workgroup per CU; a chunk must be worth its flush (kr*d doubles of atomics)
     int64_t n_chunks = 256 / n_ranges;
+    if (bs.batch > 1) n_chunks = (n_chunks + bs.batch - 1) / bs.batch < 8 ? 8 : (n_chunks + bs.batch - 1) / bs.batch;
     const int64_t min_rows = (int64_t)8 * kr + 1024;
     if (n_chunks > (n + min_rows - 1) / min_rows) n_chunks = (n + min_rows - 1) / min_rows;
     if (n_chunks < 1) n_chunks = 1;
     int64_t rows_per_chunk = (n + n_chunks - 1) / n_chunks;
     rows_per_chunk = (rows_per_chunk + 63) / 64 * 64;
     n_chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
-    const dim3 grid((unsigned)n_chunks, (unsigned)n_ranges);
+    const dim3 grid((unsigned)n_chunks, (unsigned)n_ranges, (unsigned)bs.batch);
 #define MTP_ACC_LAUNCH(LPR)                                                                                        \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
@@ -64,7 +66,7 @@ int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *label
             attr_set = true;                                                                                       \
         }                                                                                                          \
         hipLaunchKernelGGL((k_accumulate<LPR, 4, double, true>), grid, dim3(1024), lds, s, X, n, d, labels, k, kr, rows_per_chunk,    \
-                           sums, counts, state);                                                                   \
+                           sums, counts, state, bs);                                                               \
     } while (0)
     if (dq <= 8)
         MTP_ACC_LAUNCH(8);
@@ -111,11 +113,29 @@ __device__ inline float euclid_sq_sklearn(const float *a, const float *b, int d)
     return result;
 }
 
-__global__ __launch_bounds__(64) void k_mstep_centers(double *red, const float *__restrict__ C_old, float *C_new,
+__global__ __launch_bounds__(64) void k_mstep_centers(double *red, const float *C_old, float *C_new,
                                                       int k, int d, int relocation_done, float *staged, float *c2,
-                                                      float *shift, const int32_t *flags) {
+                                                      float *shift, const int32_t *flags, MtpBatchStride bs,
+                                                      int flag_parity) {
     extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // 2*d floats: new row, old row
     __shared__ int scratch[2];
+    {
+        const size_t b = blockIdx.y;
+        red += b * bs.red;
+        flags += b * bs.flags;
+        if (staged != nullptr) staged += b * bs.staged;
+        c2 += b * bs.kvec;
+        shift += b * bs.kvec;
+        const float *c0 = C_old + b * bs.c0;
+        float *c1 = C_new + b * bs.c1;
+        if (flag_parity && (flags[MTP_FLAG_N_ITER] & 1)) {  // this restart's centres live in buffer 1
+            C_old = c1;
+            C_new = const_cast<float *>(c0);
+        } else {
+            C_old = c0;
+            C_new = c1;
+        }
+    }
     if (flags[MTP_FLAG_STATE] != MTP_STATE_RUNNING) return;
     const double *counts = red + (size_t)k * d;
     const int n_empty = block_count_empty(counts, k, scratch);
@@ -154,9 +174,15 @@ __global__ __launch_bounds__(64) void k_mstep_centers(double *red, const float *
 
 __global__ __launch_bounds__(256) void k_mstep_flags(double *red, int k, int d, double tol, int max_iter,
                                                      int relocation_done, const float *shift, int32_t *flags,
-                                                     double *red_backup) {
+                                                     double *red_backup, MtpBatchStride bs) {
     __shared__ int scratch[4];
     __shared__ double dsum[4];
+    {
+        const size_t b = blockIdx.x;
+        red += b * bs.red;
+        shift += b * bs.kvec;
+        flags += b * bs.flags;
+    }
     if (flags[MTP_FLAG_STATE] != MTP_STATE_RUNNING) return;
     double *counts = red + (size_t)k * d;
     const int n_empty = block_count_empty(counts, k, scratch);
@@ -206,14 +232,15 @@ __global__ __launch_bounds__(256) void k_mstep_flags(double *red, int k, int d, 
 
 int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
                      int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, double *red_backup,
-                     hipStream_t s) {
+                     hipStream_t s, MtpBatchStride bs, int flag_parity) {
     const bool mfma = mtp_mfma_dim(d);
     const int rows = mfma ? mtp_n_tiles(k) * 32 : k;
-    hipLaunchKernelGGL(k_mstep_centers, dim3(rows), dim3(64), 2 * (size_t)d * sizeof(float), s, red, C_old, C_new, k, d,
-                       relocation_done, mfma ? staged : nullptr, c2, shift, flags);
+    MTP_REQUIRE(bs.batch == 1 || red_backup == nullptr, "mtp_lloyd_mstep: red_backup is not supported for batched restarts");
+    hipLaunchKernelGGL(k_mstep_centers, dim3(rows, bs.batch), dim3(64), 2 * (size_t)d * sizeof(float), s, red, C_old,
+                       C_new, k, d, relocation_done, mfma ? staged : nullptr, c2, shift, flags, bs, flag_parity);
     MTP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_mstep_flags, dim3(1), dim3(256), 0, s, red, k, d, tol, max_iter, relocation_done, shift,
-                       flags, red_backup);
+    hipLaunchKernelGGL(k_mstep_flags, dim3(bs.batch), dim3(256), 0, s, red, k, d, tol, max_iter, relocation_done, shift,
+                       flags, red_backup, bs);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }

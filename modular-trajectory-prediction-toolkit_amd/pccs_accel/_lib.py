@@ -38,7 +38,12 @@ SIGNATURES = {
     "mtp_apply_relocation_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mtp_lloyd_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _f64, _i32, _vp, _vp, ctypes.POINTER(ctypes.c_int), _vp,
                              _sz, _vp]),
+    "mtp_lloyd_batched_workspace_bytes": (_i64, [_i32, _i32, _i32, _i64]),
+    "mtp_lloyd_batched_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _f64, _i32, _vp, _vp,
+                                     ctypes.POINTER(ctypes.c_int), _vp, _sz, _vp]),
     "mtp_kpp_workspace_bytes": (_i64, [_i64, _i32, _i32]),
+    "mtp_kpp_batched_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32]),
+    "mtp_kmeans_plusplus_batched_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mtp_kmeans_plusplus_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mtp_best_of_k_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mtp_best_of_k_f64": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

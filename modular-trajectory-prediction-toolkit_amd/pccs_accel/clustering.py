@@ -58,14 +58,23 @@ def is_same_clustering(l1, l2, k):
     return torch.unique(pairs).numel() == torch.unique(l1).numel()
 
 
+def restart_batch(n, d, k, n_init):
+    """How many restarts share one launch.  Small problems (one Lloyd iteration is launch-bound
+    and cannot fill 256 CUs) run all restarts together; big ones gain nothing from it."""
+    if d not in (64, 96, 128):
+        return 1
+    return int(max(1, min(n_init, 4e10 // (float(n) * k * d))))
+
+
 def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, max_iter=300, tol=1e-4,
-               x_mean=None, check_every=None):
+               x_mean=None, check_every=None, batch=None):
     """sklearn ``KMeans(n_clusters, n_init=n_init, init=init).fit(X)`` on one MI355X.
 
     X: float32 device tensor [N, D] (not modified).  ``init``: 'k-means++' or a [K, D] array /
     tensor of initial centres (then one run, like sklearn).  ``random_state``: None (NumPy's
     global RandomState, so ``np.random.seed(s)`` before the call pins it, as with the
     reference), an int, or a RandomState.  ``x_mean`` overrides the column mean (tests).
+    ``batch``: restarts per launch (default: ``restart_batch``); the result does not depend on it.
     Returns dict(labels int32 [N] (device), centers float32 [K, D] (device), inertia, n_iter).
     """
     if not (isinstance(X, torch.Tensor) and X.is_cuda and X.dtype == torch.float32 and X.dim() == 2):
@@ -102,11 +111,31 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
         raise ValueError(f"init must be 'k-means++' or an array, got {init!r}")
 
     best = None
-    for _ in range(n_init):
-        c0 = c_init if init_is_array else seeding.kmeans_plusplus(Xc, n_clusters, rs)[0]
-        labels, inertia, centers, n_iter = K.lloyd(Xc, c0, max_iter=max_iter, tol_abs=tol_abs, check_every=check_every)
+
+    def consider(labels, inertia, centers, n_iter):
+        # sklearn cluster/_kmeans.py:1525-1532, restarts visited in order
+        nonlocal best
         if best is None or (inertia < best["inertia"] and not is_same_clustering(labels, best["labels"], n_clusters)):
             best = dict(labels=labels, centers=centers, inertia=inertia, n_iter=n_iter)
+
+    if batch is None:
+        batch = restart_batch(n, d, n_clusters, n_init)
+    if init_is_array or batch <= 1:
+        for _ in range(n_init):
+            c0 = c_init if init_is_array else seeding.kmeans_plusplus(Xc, n_clusters, rs)[0]
+            consider(*K.lloyd(Xc, c0, max_iter=max_iter, tol_abs=tol_abs, check_every=check_every))
+    else:
+        # the draws of every restart, in sklearn's order (seeding consumes the stream, Lloyd does not)
+        draws = [seeding.draw(rs, n, n_clusters) for _ in range(n_init)]
+        for s0 in range(0, n_init, batch):
+            c0s, _ = seeding.kmeans_plusplus_batched(Xc, n_clusters, draws[s0:s0 + batch])
+            labels, inertia, centers, n_iter = K.lloyd_batched(Xc, c0s, max_iter=max_iter, tol_abs=tol_abs,
+                                                               check_every=check_every or 4)
+            inertia = inertia.cpu().numpy()
+            for b in range(c0s.shape[0]):
+                consider(labels[b], float(inertia[b]), centers[b], n_iter[b])
+        best["labels"] = best["labels"].clone()
+        best["centers"] = best["centers"].clone()
 
     best["centers"] = best["centers"] + mean32
     distinct = int(torch.unique(best["labels"]).numel())

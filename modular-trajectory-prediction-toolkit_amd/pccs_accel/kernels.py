@@ -168,6 +168,31 @@ def lloyd(Xc, C0, max_iter=300, tol_abs=0.0, check_every=None):
     return labels, float(inert.item()), C, int(n_iter.value)
 
 
+def lloyd_batched(Xc, C0s, max_iter=300, tol_abs=0.0, check_every=4):
+    """``C0s.shape[0]`` independent ``lloyd`` runs on the same centred points, sharing every launch
+    (the n_init restarts of KMeans.fit).  C0s [B, K, D].  Returns (labels int32 [B, N],
+    inertia float64 [B] (device), centers float32 [B, K, D], n_iter list of B ints)."""
+    _req(Xc, "X", torch.float32, 2)
+    _req(C0s, "C0s", torch.float32, 3)
+    n, d = Xc.shape
+    b, k, d2 = C0s.shape
+    if d2 != d:
+        raise ValueError(f"C0s has {d2} features, X has {d}")
+    if n < k:
+        raise ValueError(f"n_samples={n} should be >= n_clusters={k}.")
+    C = C0s.clone()
+    labels = torch.empty((b, n), dtype=torch.int32, device=Xc.device)
+    inert = torch.zeros(b, dtype=torch.float64, device=Xc.device)
+    ws_bytes = int(lib().mtp_lloyd_batched_workspace_bytes(k, d, b, n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Xc.device)
+    n_iter = (ctypes.c_int * b)()
+    with torch.cuda.device(Xc.device):
+        check(lib().mtp_lloyd_batched_f32(ptr(Xc), n, d, ptr(C), k, b, int(max_iter), float(tol_abs), int(check_every),
+                                          ptr(labels), ptr(inert), n_iter, ptr(ws), ws_bytes, stream_ptr()),
+              "mtp_lloyd_batched_f32")
+    return labels, inert, C, [int(v) for v in n_iter]
+
+
 def best_of_k(pred, gt, mode=0, ade_div=None, best_of=None, want_per_agent=True):
     """pred [N, Ktot, T, 2], gt [N, T, 2] (float32 or float64, same dtype).
 

@@ -42,3 +42,44 @@ def kmeans_plusplus(Xc, n_clusters, random_state, n_local_trials=None):
                                             ptr(indices), ptr(centers), ptr(ws), ws_bytes, stream_ptr()),
               "mtp_kmeans_plusplus_f32")
     return centers, indices
+
+
+def draw(random_state, n, n_clusters, n_local_trials=None):
+    """The random numbers one ``_kmeans_plusplus`` call consumes, in sklearn's order:
+    (first centre index, uniform [K-1, L])."""
+    if n_local_trials is None:
+        n_local_trials = 2 + int(np.log(n_clusters))
+    w = np.ones(n, dtype=np.float32)
+    center_id = int(random_state.choice(n, p=w / w.sum()))
+    u = random_state.uniform(size=(max(n_clusters - 1, 0), n_local_trials))
+    return center_id, u
+
+
+def kmeans_plusplus_batched(Xc, n_clusters, draws):
+    """Seeding of len(draws) restarts in shared launches.  ``draws``: list of ``draw()`` results,
+    one per restart, taken from the RandomState in restart order.  Returns (centers float32
+    [B, K, D], indices int64 [B, K]) device tensors."""
+    if not (isinstance(Xc, torch.Tensor) and Xc.is_cuda and Xc.dtype == torch.float32 and Xc.dim() == 2
+            and Xc.is_contiguous()):
+        raise TypeError("kmeans_plusplus_batched expects a contiguous float32 HIP device tensor [N, D]")
+    n, d = Xc.shape
+    dev = Xc.device
+    b = len(draws)
+    l = draws[0][1].shape[1] if n_clusters > 1 else 2 + int(np.log(n_clusters))
+    ids = np.asarray([c for c, _ in draws], dtype=np.int64)
+    if ids.min() < 0 or ids.max() >= n:
+        raise ValueError("first-centre index out of range")
+    ids_dev = torch.from_numpy(ids).to(dev)
+    u_dev = None
+    if n_clusters > 1:
+        u = np.ascontiguousarray(np.stack([u for _, u in draws]).reshape(-1))
+        u_dev = torch.from_numpy(u).to(dev)
+    indices = torch.empty((b, n_clusters), dtype=torch.int64, device=dev)
+    centers = torch.empty((b, n_clusters, d), dtype=torch.float32, device=dev)
+    ws_bytes = int(lib().mtp_kpp_batched_workspace_bytes(n, d, l, b))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().mtp_kmeans_plusplus_batched_f32(ptr(Xc), n, d, n_clusters, l, b, ptr(ids_dev), ptr(u_dev), ptr(indices),
+                                                    ptr(centers), ptr(ws), ws_bytes, stream_ptr()),
+              "mtp_kmeans_plusplus_batched_f32")
+    return centers, indices

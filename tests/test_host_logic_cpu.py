@@ -95,4 +95,33 @@ def test_modules_mirror_reference_names():
         assert callable(getattr(U, name))
     for name in ("displacement_error", "final_displacement_error"):
         assert callable(getattr(M, name))
-    from pccs_accel.evaluation import best_of_k, evaluate  # noqa: F401
+    from pccs_accel.evaluation import best_of_k, evaluate, gen_prediction, predict_topk  # noqa: F401
+    import pccs_accel.utils.checkings as Ck
+    import pccs_accel.utils.data_process as D
+    for name in ("transform_trajectory", "process_scene", "gen_prob", "get_scene_data"):
+        assert callable(getattr(D, name))
+    for name in ("check_memory_consistency", "check_cluster_consistency", "check_prob_consistency"):
+        assert callable(getattr(Ck, name))
+    from pccs_accel.rerank import nms_rerank, rerank_predictions, verify_and_evaluate  # noqa: F401
+
+
+def test_restart_batching_rule():
+    from pccs_accel.clustering import restart_batch
+    assert restart_batch(73568, 96, 200, 20) == 20        # reference scale: all restarts share the launches
+    assert restart_batch(17970, 96, 400, 20) == 20
+    assert restart_batch(10_000_000, 128, 1024, 20) == 1  # one restart already fills the GPU
+    assert restart_batch(73568, 50, 200, 20) == 1         # generic (non-MFMA) feature size
+
+
+def test_seeding_draw_order_matches_sklearn_stream():
+    """seeding.draw consumes the RandomState exactly like sklearn's _kmeans_plusplus: one choice,
+    then uniform(size=L) per further centre (drawn as one [K-1, L] block: same stream)."""
+    import numpy as np
+    from pccs_accel import seeding
+    rs1, rs2 = np.random.RandomState(3), np.random.RandomState(3)
+    cid, u = seeding.draw(rs1, 500, 9)
+    w = np.ones(500, dtype=np.float32)
+    assert cid == rs2.choice(500, p=w / w.sum())
+    for c in range(8):
+        assert np.array_equal(u[c], rs2.uniform(size=2 + int(np.log(9))))
+    assert rs1.randint(1 << 30) == rs2.randint(1 << 30)   # both streams are at the same position

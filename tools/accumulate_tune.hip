@@ -49,7 +49,7 @@ void launch_v(const float *X, int64_t n, int d, const int32_t *labels, int k, do
     rpc = (rpc + 63) / 64 * 64;
     n_chunks = (n + rpc - 1) / rpc;
     hipLaunchKernelGGL((k_accumulate<LPR, G, ACC, DO_ADD>), dim3((unsigned)n_chunks, (unsigned)n_ranges), dim3(c.threads),
-                       lds, 0, X, n, d, labels, k, kr, rpc, sums, counts, nullptr);
+                       lds, 0, X, n, d, labels, k, kr, rpc, sums, counts, nullptr, mtp_no_batch());
     CK(hipGetLastError());
 }
 
