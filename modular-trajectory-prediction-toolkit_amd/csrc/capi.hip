@@ -1,4 +1,5 @@
 // C-ABI entry points of libmtp_accel.so (see include/mtp_accel.h) and the single-GPU Lloyd driver.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -319,6 +320,11 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
             } else if (f[MTP_FLAG_STATE] == MTP_STATE_RUNNING) {
                 any_live = true;
             }
+        }
+        if (getenv("MTP_DEBUG")) {
+            fprintf(stderr, "[mtp_lloyd_batched] round %d states:", round);
+            for (int b = 0; b < batch; ++b) fprintf(stderr, " %d/%d", hflags[(size_t)b * MTP_FLAG_WORDS], hflags[(size_t)b * MTP_FLAG_WORDS + 1]);
+            fprintf(stderr, "\n");
         }
         if (!any_live) break;
     }

@@ -17,9 +17,9 @@
 // np.cumsum / the BLAS sums are replaced by double tree sums: differences ~1e-16 relative.
 #include "mtp_internal.h"
 
-static constexpr int KPP_PB = 256;     // points per block of k_kpp_dist (one per thread)
-static constexpr int KPP_Q = KPP_PB / 64;  // points per lane in the in-block scan
-static constexpr int KPP_MAX_L = 16;   // local trials: 2 + int(ln K) <= 16 up to K ~ 1.2e6
+static constexpr int KPP_PB = 256;     // points per block sum of k_kpp_dist (one per thread); the tiled kernel uses 128
+static constexpr int KPP_MAX_L = 16;
+__host__ __device__ inline int kpp_ltile(int l) { return l <= 8 ? 8 : 16; }   // local trials: 2 + int(ln K) <= 16 up to K ~ 1.2e6
 
 // Restarts are batched along blockIdx.y: restart b uses the pointers below moved by b * stride
 // bytes (yy is shared: it only depends on X).
@@ -37,7 +37,8 @@ struct KppWs {
     float *rows;       // [2][L][n] closest-distance rows (ping-pong over steps)
     double *bsum;      // [2][L][nblk] per-block sums of those rows
     double *prefix;    // [nblk] scratch: inclusive prefix of the selected row's block sums
-    double *cand_x;    // [L][d] candidate rows in double
+    double *cand_x;    // [d][LTILE] candidate rows in double, feature-major: element k of candidate l at k*LTILE + l
+                       // (LTILE = 8 or 16), so one scalar load brings the k-th element of a whole candidate tile
     double *cand_xx;   // [L]
     int64_t *cand;     // [L] candidate ids
     int32_t *state;    // [0] = selected candidate of the current rows
@@ -50,7 +51,7 @@ static inline size_t kpp_align(size_t v) { return (v + 255) / 256 * 256; }
 
 static KppWs kpp_carve(void *ws, int64_t n, int d, int l, int batch) {
     KppWs w;
-    const int64_t nblk = (n + KPP_PB - 1) / KPP_PB;
+    const int64_t nblk = (n + 127) / 128;  // sized for the smaller of the two block-sum granularities
     size_t off = 0;
     auto take = [&](size_t bytes) {
         void *p = ws ? static_cast<char *>(ws) + off : nullptr;
@@ -62,7 +63,8 @@ static KppWs kpp_carve(void *ws, int64_t n, int d, int l, int batch) {
     w.rows = static_cast<float *>(take((size_t)2 * l * n * 4));
     w.bsum = static_cast<double *>(take((size_t)2 * l * nblk * 8));
     w.prefix = static_cast<double *>(take((size_t)nblk * 8));
-    w.cand_x = static_cast<double *>(take((size_t)l * d * 8));
+    // padded to the kernels' candidate tile (8 or 16 rows): k_kpp_dist_reg multiplies all rows of the tile
+    w.cand_x = static_cast<double *>(take((size_t)kpp_ltile(l) * d * 8));
     w.cand_xx = static_cast<double *>(take((size_t)l * 8));
     w.cand = static_cast<int64_t *>(take((size_t)l * 8));
     w.state = static_cast<int32_t *>(take(64));
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void k_kpp_dist(const float *__restrict__ X, i
                                                   const double *__restrict__ cand_xx, const double *__restrict__ yy,
                                                   const float *rows_prev /* [L][n] */, const int32_t *sel_prev,
                                                   int has_prev, float *rows_out /* [L][n] */, double *bsum_out,
-                                                  int64_t nblk, size_t bstride) {
+                                                  int64_t nblk, size_t bstride, int ltile) {
     extern __shared__ __attribute__((aligned(16))) double sx[];  // LT * d candidate rows (zero padded)
     __shared__ double part[LT][4];
     {
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void k_kpp_dist(const float *__restrict__ X, i
         rows_out = kpp_at(rows_out, bstride, b);
         bsum_out = kpp_at(bsum_out, bstride, b);
     }
-    for (int e = threadIdx.x; e < LT * d; e += 256) sx[e] = e < n_cand * d ? cand_x[e] : 0.0;
+    for (int e = threadIdx.x; e < LT * d; e += 256) sx[e] = e < n_cand * d ? cand_x[(size_t)(e % d) * ltile + e / d] : 0.0;
     __syncthreads();
     const float *prev = has_prev ? rows_prev + (size_t)(*sel_prev) * n : nullptr;
     double acc[LT];
@@ -161,18 +163,179 @@ __global__ __launch_bounds__(256) void k_kpp_dist(const float *__restrict__ X, i
     }
 }
 
+
+// The same computation as a register-tiled double-precision GEMM (feature sizes that are multiples of
+// 16, at most 8 local trials).  A workgroup computes 128 points x (16 * CQ) candidates -- the
+// candidate tiles of 2 * CQ restarts side by side -- from LDS chunks of 16 features; a thread owns
+// an 8 x CQ block of accumulators (points tx + 16 p, candidates ty * CQ + q), so every multiply-add
+// costs (8 + CQ) / (8 CQ) LDS reads instead of one, X is read once for all those restarts, and the
+// candidate rows once per workgroup.  Per (candidate, point) the features are still accumulated
+// one fma at a time in ascending k: the same bits as k_kpp_dist.  Block sums: a thread's 8 points
+// in order, then a 16-lane shuffle tree.
+static constexpr int KPP_TP = 128;  // points per workgroup == points per block sum on this path
+static constexpr int KPP_KC = 16;   // features per LDS chunk
+
+template <int CQ>
+__global__ __launch_bounds__(256, 2) void k_kpp_dist_tile(const float *__restrict__ X, int64_t n, int d, int n_cand,
+                                                       const double *__restrict__ cand_x0,
+                                                       const double *__restrict__ cand_xx0,
+                                                       const double *__restrict__ yy, const float *rows_prev0,
+                                                       const int32_t *sel_prev0, int has_prev, float *rows_out0,
+                                                       double *bsum_out0, int64_t nblk, size_t bstride, int batch) {
+    constexpr int NC = 16 * CQ;      // candidate columns of the tile (8 per restart)
+    constexpr int RB = 2 * CQ;       // restarts per workgroup
+    __shared__ __attribute__((aligned(16))) double ys[KPP_KC][KPP_TP + 2];
+    __shared__ __attribute__((aligned(16))) double cs[KPP_KC][NC];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * KPP_TP;
+    const int b0 = blockIdx.y * RB;
+    double acc[8][CQ];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) acc[p][q] = 0.0;
+
+    for (int kc = 0; kc < d; kc += KPP_KC) {
+        // X chunk: 128 rows x KPP_KC floats, converted once, stored feature-major
+        for (int e = tid; e < KPP_TP * (KPP_KC / 4); e += 256) {
+            const int r = e / (KPP_KC / 4), q4 = e % (KPP_KC / 4);
+            int64_t row = row0 + r;
+            if (row >= n) row = n - 1;
+            const float4 v = *reinterpret_cast<const float4 *>(X + row * d + kc + 4 * q4);
+            ys[4 * q4 + 0][r] = (double)v.x;
+            ys[4 * q4 + 1][r] = (double)v.y;
+            ys[4 * q4 + 2][r] = (double)v.z;
+            ys[4 * q4 + 3][r] = (double)v.w;
+        }
+        // candidate chunk: restart rb's rows kc..kc+KPP_KC-1 are KPP_KC x 8 contiguous doubles (feature-major)
+        for (int e = tid; e < RB * KPP_KC * 8; e += 256) {
+            const int rb = e / (KPP_KC * 8), w = e % (KPP_KC * 8);
+            const int b = b0 + rb;
+            cs[w >> 3][rb * 8 + (w & 7)] = b < batch ? kpp_at(cand_x0, bstride, b)[(size_t)kc * 8 + w] : 0.0;
+        }
+        __syncthreads();
+        // operands of step kk+1 are read from LDS while the 8*CQ multiply-adds of step kk issue
+        double yv[8], cv[CQ];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) yv[p] = ys[0][tx + 16 * p];
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) cv[q] = cs[0][ty * CQ + q];
+#pragma unroll
+        for (int kk = 0; kk < KPP_KC; ++kk) {
+            double yn[8], cn[CQ];
+            if (kk + 1 < KPP_KC) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) yn[p] = ys[kk + 1][tx + 16 * p];
+#pragma unroll
+                for (int q = 0; q < CQ; ++q) cn[q] = cs[kk + 1][ty * CQ + q];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the reads above are in flight during the FMAs below
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int q = 0; q < CQ; ++q) acc[p][q] = fma(cv[q], yv[p], acc[p][q]);
+            if (kk + 1 < KPP_KC) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) yv[p] = yn[p];
+#pragma unroll
+                for (int q = 0; q < CQ; ++q) cv[q] = cn[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: distance, clamp, min with the closest-so-far row, store, block sums.  All loads
+    // (||y||^2, the previous closest rows) are issued before the first store: rows_out may alias
+    // nothing here, but the compiler cannot know and would otherwise serialise load -> store per
+    // candidate.
+    double yyv[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int64_t i = row0 + tx + 16 * p;
+        yyv[p] = yy[i < n ? i : n - 1];
+    }
+    float oldv[CQ][8];
+    double cxx[CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+        const int col = ty * CQ + q;
+        const int b = b0 + (col >> 3), l = col & 7;
+        const bool use = b < batch && l < n_cand;
+        cxx[q] = use ? kpp_at(cand_xx0, bstride, b)[l] : 0.0;
+        const float *prev = (use && has_prev)
+                                ? kpp_at(rows_prev0, bstride, b) + (size_t)(*kpp_at(sel_prev0, bstride, b)) * n
+                                : nullptr;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int64_t i = row0 + tx + 16 * p;
+            oldv[q][p] = (prev != nullptr && i < n) ? prev[i] : __builtin_inff();
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+        const int col = ty * CQ + q;
+        const int b = b0 + (col >> 3), l = col & 7;
+        const bool use = b < batch && l < n_cand;  // uniform per 16-lane group
+        double sum = 0.0;
+        if (use) {
+            float *rows_out = kpp_at(rows_out0, bstride, b) + (size_t)l * n;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int64_t i = row0 + tx + 16 * p;
+                if (i < n) {
+                    double dd = -2.0 * acc[p][q];
+                    dd += cxx[q];
+                    dd += yyv[p];
+                    float f = (float)dd;
+                    f = f > 0.f ? f : 0.f;                        // np.maximum(d, 0)
+                    f = f < oldv[q][p] ? f : oldv[q][p];          // np.minimum(closest_dist_sq, distance_to_candidates)
+                    rows_out[i] = f;
+                    sum += (double)f;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+        if (use && tx == 0) kpp_at(bsum_out0, bstride, b)[(size_t)l * nblk + blockIdx.x] = sum;
+    }
+}
+
+template <int CQ>
+static void launch_kpp_dist_tile(const float *X, int64_t n, int d, int n_cand, const KppWs &w, const float *rows_prev,
+                                 int has_prev, float *rows_out, double *bsum_out, int64_t nblk, int batch,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL((k_kpp_dist_tile<CQ>), dim3((unsigned)nblk, (unsigned)((batch + 2 * CQ - 1) / (2 * CQ))), dim3(256),
+                       0, s, X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out,
+                       nblk, w.stride, batch);
+}
+
+__host__ inline bool kpp_tile_path(int d, int l) { return d % KPP_KC == 0 && l <= 8; }
+
 static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const KppWs &w, const float *rows_prev,
-                           int has_prev, float *rows_out, double *bsum_out, int64_t nblk, int batch, hipStream_t s) {
+                           int has_prev, float *rows_out, double *bsum_out, int64_t nblk, int batch, int ltile,
+                           hipStream_t s) {
     const dim3 grid((unsigned)nblk, (unsigned)batch), block(256);
+    if (kpp_tile_path(d, ltile == 8 ? 8 : 16)) {
+        // candidates per thread: 10 covers the reference's 20 restarts in one workgroup column
+        if (batch > 8)
+            launch_kpp_dist_tile<5>(X, n, d, n_cand, w, rows_prev, has_prev, rows_out, bsum_out, nblk, batch, s);
+        else if (batch > 2)
+            launch_kpp_dist_tile<4>(X, n, d, n_cand, w, rows_prev, has_prev, rows_out, bsum_out, nblk, batch, s);
+        else
+            launch_kpp_dist_tile<1>(X, n, d, n_cand, w, rows_prev, has_prev, rows_out, bsum_out, nblk, batch, s);
+        MTP_LAUNCH_CHECK();
+        return MTP_OK;
+    }
     if (n_cand == 1)
         hipLaunchKernelGGL(k_kpp_dist<1>, grid, block, (size_t)1 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy,
-                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride);
+                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride, ltile);
     else if (n_cand <= 8)
         hipLaunchKernelGGL(k_kpp_dist<8>, grid, block, (size_t)8 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy,
-                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride);
+                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride, ltile);
     else
         hipLaunchKernelGGL(k_kpp_dist<16>, grid, block, (size_t)16 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx,
-                           w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride);
+                           w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride, ltile);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
@@ -180,13 +343,14 @@ static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const K
 // One workgroup of 1024 threads.  (1) potentials of the n_prev candidate rows = sums of their block
 // sums; best = first argmin (float32 compare like np.argmin on the float32 potentials); record the
 // chosen centre.  (2) if n_new > 0: draw positions for the next n_new candidates.
+template <int KPP_Q>
 __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X, int64_t n, int d, int n_prev,
                                                      int n_new, const double *__restrict__ u /* [n_new] */,
                                                      const float *rows_cur, const double *bsum_cur, int64_t nblk,
                                                      double *prefix, int64_t *cand, double *cand_x, double *cand_xx,
                                                      int32_t *state, float *pot_out, int64_t *index_out,
                                                      size_t bstride, size_t u_stride /* doubles */,
-                                                     size_t index_stride /* int64s */) {
+                                                     size_t index_stride /* int64s */, int ltile) {
     {
         const int b = blockIdx.x;
         if (u != nullptr) u += u_stride * b;
@@ -274,7 +438,8 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
         int64_t id = n - 1;
         if (blk < nblk) {
             const double start = blk > 0 ? prefix[blk - 1] : 0.0;
-            const int64_t p0 = (int64_t)blk * KPP_PB + lane * KPP_Q;
+            constexpr int PB = 64 * KPP_Q;  // points per block sum
+            const int64_t p0 = (int64_t)blk * PB + lane * KPP_Q;
             double loc[KPP_Q];
             double s = 0.0;
 #pragma unroll
@@ -297,11 +462,11 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
             if (mask) {
                 const int wl = (int)__builtin_ctzll(mask);
                 const int fq = __shfl(first, wl);
-                const int64_t cid = (int64_t)blk * KPP_PB + wl * KPP_Q + fq;
+                const int64_t cid = (int64_t)blk * PB + wl * KPP_Q + fq;
                 id = cid < n ? cid : n - 1;
             } else {
                 // rounding put the draw past this block's end: first point of the next block
-                const int64_t cid = (int64_t)(blk + 1) * KPP_PB;
+                const int64_t cid = (int64_t)(blk + 1) * PB;
                 id = cid < n ? cid : n - 1;
             }
         }
@@ -311,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
         double xx = 0.0;
         for (int k = lane; k < d; k += 64) {
             const double v = (double)x[k];
-            cand_x[(size_t)l * d + k] = v;
+            cand_x[(size_t)k * ltile + l] = v;
             xx += v * v;
         }
         for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
@@ -321,7 +486,7 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
 
 __global__ __launch_bounds__(64) void k_kpp_first(const float *__restrict__ X, int d, int64_t center_id,
                                                   const int64_t *center_ids, int64_t *cand, double *cand_x,
-                                                  double *cand_xx, size_t bstride) {
+                                                  double *cand_xx, size_t bstride, int ltile) {
     const int lane = threadIdx.x;
     if (center_ids != nullptr) center_id = center_ids[blockIdx.x];
     cand = kpp_at(cand, bstride, blockIdx.x);
@@ -331,7 +496,7 @@ __global__ __launch_bounds__(64) void k_kpp_first(const float *__restrict__ X, i
     double xx = 0.0;
     for (int k = lane; k < d; k += 64) {
         const double v = (double)x[k];
-        cand_x[k] = v;
+        cand_x[(size_t)k * ltile] = v;
         xx += v * v;
     }
     for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
@@ -367,15 +532,18 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
         return MTP_E_WORKSPACE;
     }
     hipStream_t s = mtp_stream(stream);
-    const int64_t nblk = (n + KPP_PB - 1) / KPP_PB;
+    const bool tile = kpp_tile_path(d, l);
+    const int pb = tile ? KPP_TP : KPP_PB;  // points per block sum
+    const int64_t nblk = (n + pb - 1) / pb;
     MTP_REQUIRE(nblk <= 0x7fffffff, "mtp_kmeans_plusplus: n too large");
     hipLaunchKernelGGL(k_kpp_rownorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, n, d, w.yy);
     MTP_LAUNCH_CHECK();
+    const int ltile = kpp_ltile(l);
     hipLaunchKernelGGL(k_kpp_first, dim3(batch), dim3(64), 0, s, X, d, center_id, center_ids_dev, w.cand, w.cand_x,
-                       w.cand_xx, w.stride);
+                       w.cand_xx, w.stride, ltile);
     MTP_LAUNCH_CHECK();
     // closest distances to the first centre: one "candidate", no previous row
-    int rc = launch_kpp_dist(X, n, d, 1, w, nullptr, 0, w.rows, w.bsum, nblk, batch, s);
+    int rc = launch_kpp_dist(X, n, d, 1, w, nullptr, 0, w.rows, w.bsum, nblk, batch, ltile, s);
     if (rc != MTP_OK) return rc;
     int cur = 0, n_prev = 1;
     const size_t u_stride = (size_t)(k - 1) * l;
@@ -384,14 +552,21 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
         const int n_new = c < k ? l : 0;
         float *rows_cur = w.rows + (size_t)cur * l * n;
         double *bsum_cur = w.bsum + (size_t)cur * l * nblk;
-        hipLaunchKernelGGL(k_kpp_select, dim3(batch), dim3(1024), 0, s, X, n, d, n_prev, n_new,
-                           c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
-                           w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1), w.stride, u_stride, (size_t)k);
+        if (tile)
+            hipLaunchKernelGGL(k_kpp_select<KPP_TP / 64>, dim3(batch), dim3(1024), 0, s, X, n, d, n_prev, n_new,
+                               c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
+                               w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1), w.stride, u_stride, (size_t)k,
+                               ltile);
+        else
+            hipLaunchKernelGGL(k_kpp_select<KPP_PB / 64>, dim3(batch), dim3(1024), 0, s, X, n, d, n_prev, n_new,
+                               c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
+                               w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1), w.stride, u_stride, (size_t)k,
+                               ltile);
         MTP_LAUNCH_CHECK();
         if (c == k) break;
         float *rows_nxt = w.rows + (size_t)(cur ^ 1) * l * n;
         double *bsum_nxt = w.bsum + (size_t)(cur ^ 1) * l * nblk;
-        rc = launch_kpp_dist(X, n, d, l, w, rows_cur, 1, rows_nxt, bsum_nxt, nblk, batch, s);
+        rc = launch_kpp_dist(X, n, d, l, w, rows_cur, 1, rows_nxt, bsum_nxt, nblk, batch, ltile, s);
         if (rc != MTP_OK) return rc;
         cur ^= 1;
         n_prev = l;

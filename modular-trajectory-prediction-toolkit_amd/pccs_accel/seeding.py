@@ -29,9 +29,7 @@ def kmeans_plusplus(Xc, n_clusters, random_state, n_local_trials=None):
     dev = Xc.device
     if n_local_trials is None:
         n_local_trials = 2 + int(np.log(n_clusters))
-    w = np.ones(n, dtype=np.float32)
-    center_id = int(random_state.choice(n, p=w / w.sum()))
-    u = random_state.uniform(size=(max(n_clusters - 1, 0), n_local_trials))
+    center_id, u = draw(random_state, n, n_clusters, n_local_trials)
     u_dev = torch.from_numpy(np.ascontiguousarray(u.reshape(-1))).to(dev) if u.size else None
     indices = torch.empty(n_clusters, dtype=torch.int64, device=dev)
     centers = torch.empty((n_clusters, d), dtype=torch.float32, device=dev)
@@ -44,13 +42,28 @@ def kmeans_plusplus(Xc, n_clusters, random_state, n_local_trials=None):
     return centers, indices
 
 
+_CDF = {}
+
+
+def _uniform_cdf(n):
+    """The cdf ``RandomState.choice(n, p=w / w.sum())`` builds for unit float32 weights
+    (numpy/random/mtrand.pyx: p -> float64, cdf = p.cumsum(); cdf /= cdf[-1]); it only depends on n."""
+    if n not in _CDF:
+        _CDF.clear()
+        w = np.ones(n, dtype=np.float32)
+        cdf = (w / w.sum()).astype(np.float64).cumsum()
+        cdf /= cdf[-1]
+        _CDF[n] = cdf
+    return _CDF[n]
+
+
 def draw(random_state, n, n_clusters, n_local_trials=None):
     """The random numbers one ``_kmeans_plusplus`` call consumes, in sklearn's order:
-    (first centre index, uniform [K-1, L])."""
+    (first centre index, uniform [K-1, L]).  ``choice(n, p=...)`` is one ``random_sample()``
+    looked up in the cdf (side='right'); done that way the O(n) cdf is built once, not per restart."""
     if n_local_trials is None:
         n_local_trials = 2 + int(np.log(n_clusters))
-    w = np.ones(n, dtype=np.float32)
-    center_id = int(random_state.choice(n, p=w / w.sum()))
+    center_id = int(_uniform_cdf(n).searchsorted(random_state.random_sample(), side="right"))
     u = random_state.uniform(size=(max(n_clusters - 1, 0), n_local_trials))
     return center_id, u
 

@@ -118,10 +118,12 @@ def test_seeding_draw_order_matches_sklearn_stream():
     then uniform(size=L) per further centre (drawn as one [K-1, L] block: same stream)."""
     import numpy as np
     from pccs_accel import seeding
-    rs1, rs2 = np.random.RandomState(3), np.random.RandomState(3)
-    cid, u = seeding.draw(rs1, 500, 9)
-    w = np.ones(500, dtype=np.float32)
-    assert cid == rs2.choice(500, p=w / w.sum())
-    for c in range(8):
-        assert np.array_equal(u[c], rs2.uniform(size=2 + int(np.log(9))))
-    assert rs1.randint(1 << 30) == rs2.randint(1 << 30)   # both streams are at the same position
+    for seed, n in ((3, 500), (4, 73568), (5, 17970), (6, 3)):
+        rs1, rs2 = np.random.RandomState(seed), np.random.RandomState(seed)
+        w = np.ones(n, dtype=np.float32)
+        for _ in range(40 if n < 1000 else 4):           # consecutive restarts on one stream
+            cid, u = seeding.draw(rs1, n, 9 if n > 9 else 2)
+            assert cid == rs2.choice(n, p=w / w.sum())
+            for c in range(u.shape[0]):
+                assert np.array_equal(u[c], rs2.uniform(size=u.shape[1]))
+        assert rs1.randint(1 << 30) == rs2.randint(1 << 30)   # both streams are at the same position
