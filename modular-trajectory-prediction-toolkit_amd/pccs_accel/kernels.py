@@ -330,6 +330,8 @@ def gather_candidates(pred, order):
     m = order.shape[1]
     if order.shape[0] != n or m > mtot:
         raise ValueError(f"order {tuple(order.shape)} does not fit pred {tuple(pred.shape)}")
+    if n and (int(order.min()) < 0 or int(order.max()) >= mtot):
+        raise IndexError(f"order holds candidate indices outside [0, {mtot})")
     out = torch.empty_like(pred)
     fn = lib().mtp_gather_candidates_f32 if pred.dtype == torch.float32 else lib().mtp_gather_candidates_f64
     with torch.cuda.device(pred.device):
@@ -350,6 +352,8 @@ def best_of_k_reranked(pred, gt, order, mode=0, ade_div=None, best_of=None):
     k = order.shape[1] if best_of is None else int(best_of)
     if not (1 <= k <= order.shape[1]):
         raise ValueError(f"best_of={k} must be in [1, {order.shape[1]}]")
+    if n and (int(order.min()) < 0 or int(order.max()) >= ktot):  # the kernel indexes pred with these
+        raise IndexError(f"order holds candidate indices outside [0, {ktot})")
     if ade_div is None:
         ade_div = t
     dev = pred.device

@@ -74,6 +74,11 @@ def soft_labels(offsets, ids, cluster_result, n_cluster):
     if n and (int(labels.min()) < 0 or int(labels.max()) >= n_cluster):
         raise IndexError(f"cluster_result holds labels outside [0, {n_cluster})")
     ids = ids.to(torch.int64).contiguous()
+    if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= n):  # the kernel indexes labels with these
+        raise IndexError(f"neighbour ids outside [0, {n})")
+    off_h = offsets.cpu()
+    if int(off_h[0]) != 0 or int(off_h[-1]) != ids.numel() or bool((off_h[1:] < off_h[:-1]).any()):
+        raise ValueError("offsets must rise from 0 to len(ids)")
     dense = torch.empty((n, n_cluster), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         check(lib().mtp_soft_labels_f64(ptr(offsets), ptr(ids) if ids.numel() else None, ptr(labels), n, int(n_cluster),

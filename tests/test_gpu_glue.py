@@ -324,3 +324,21 @@ def test_scene_neighbours_shapes_vs_oracle(sizes, rad, gpu_device):
     assert np.allclose(dense.sum(axis=1), 1.0)
     with pytest.raises(IndexError):
         scene.soft_labels(offsets, ids, labels, 36 if labels.max() == 36 else int(labels.max()))
+
+
+def test_index_inputs_are_validated_on_the_host(gpu_device):
+    """Index arrays that a kernel dereferences are range-checked before the launch."""
+    from pccs_accel import kernels as K
+    from pccs_accel import scene
+    pred = torch.zeros((2, 5, 12, 2), device=gpu_device)
+    gt = torch.zeros((2, 12, 2), device=gpu_device)
+    bad = torch.tensor([[0, 1, 5], [0, 1, 2]], dtype=torch.int32, device=gpu_device)
+    with pytest.raises(IndexError):
+        K.best_of_k_reranked(pred, gt, bad)
+    with pytest.raises(IndexError):
+        K.gather_candidates(pred, bad)
+    off = torch.tensor([0, 1, 2], dtype=torch.int64, device=gpu_device)
+    with pytest.raises(IndexError):
+        scene.soft_labels(off, torch.tensor([1, 2], dtype=torch.int64, device=gpu_device), np.zeros(2, np.int32), 3)
+    with pytest.raises(ValueError):
+        scene.soft_labels(off, torch.tensor([1], dtype=torch.int64, device=gpu_device), np.zeros(2, np.int32), 3)
