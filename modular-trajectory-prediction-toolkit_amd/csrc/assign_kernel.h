@@ -1,5 +1,7 @@
 // The fp32-MFMA E-step kernel (included by assign.hip and by tools/assign_tune.hip).
 #pragma once
+#include <type_traits>
+
 #include "mtp_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -196,6 +198,161 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
             labels[row] = lab;
             changed += (old != lab);
         }
+    }
+    if (n_changed != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) changed += __shfl_xor(changed, o);
+        if (lane == 0 && changed != 0) atomicAdd(n_changed, (double)changed);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Software-pipelined variant (one 32-point tile per wave, two centroid tiles per LDS stage): the
+// bias / argmin epilogue of tile i is issued BETWEEN the MFMAs of tile i+1 (two accumulator sets),
+// so its ~64 vector ops run while the matrix pipe works instead of leaving the wave's share of the
+// pipe idle.  ||c||^2 of all tiles is copied to a persistent LDS array first, because the stage
+// buffer a deferred epilogue would read it from is already being refilled by then.  Same
+// arithmetic in the same order per (point, centroid) as k_assign_mfma: same labels.
+// Dynamic LDS: 2 * STAGE_F floats + 32 * n_tiles floats.
+// ------------------------------------------------------------------------------------------
+template <int D, int WPB, int WPS, int LG = 8>
+__global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma_pipe(const float *__restrict__ X, int64_t n,
+                                                             const float *__restrict__ staged, int n_tiles,
+                                                             int32_t *__restrict__ labels, double *n_changed,
+                                                             const int32_t *state, MtpBatchStride bs) {
+    constexpr int CTW = 2;
+    constexpr int R = D / 4;
+    constexpr int U = D / 8;                 // u-steps (4 MFMAs each) per tile
+    constexpr int TILE_F = 32 * (D + 4) + 32;
+    constexpr int STAGE_F = CTW * TILE_F;
+    constexpr int STAGE_SLOTS = STAGE_F / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *c2all = smem + 2 * STAGE_F;
+    {
+        const size_t b = blockIdx.y;
+        staged += b * bs.staged;
+        labels += b * bs.labels;
+        if (n_changed != nullptr) n_changed += b * bs.red;
+        if (state != nullptr) state += b * bs.flags;
+    }
+    if (mtp_skip(state, bs.skip_mode)) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t pbase = ((int64_t)blockIdx.x * WPB + wave) * 32;
+
+    float xr[D / 2];
+    {
+        int64_t row = pbase + j;
+        if (row >= n) row = n - 1;
+        const float4 *xp = reinterpret_cast<const float4 *>(X + row * D);
+#pragma unroll
+        for (int q0 = 0; q0 < D / 4; q0 += LG) {
+            float4 v[LG];
+#pragma unroll
+            for (int g = 0; g < LG; ++g) v[g] = xp[q0 + g];
+#pragma unroll
+            for (int g = 0; g < LG; ++g) {
+                const int q = q0 + g;
+                xr[2 * q] = h ? v[g].y : v[g].x;
+                xr[2 * q + 1] = h ? v[g].w : v[g].z;
+                pin2(xr[2 * q], xr[2 * q + 1]);
+            }
+        }
+    }
+    for (int e = tid; e < n_tiles * 32; e += 64 * WPB)
+        c2all[e] = staged[(size_t)(e >> 5) * TILE_F + 32 * (D + 4) + (e & 31)];
+
+    float best = __builtin_inff();
+    int breg = 0, btile = 0;
+
+    const int n_stages = n_tiles / CTW;
+    const int wave_slot0 = wave * 64;
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    auto stage = [&](int t) {
+        const float *g = staged + (size_t)t * STAGE_F;
+        const unsigned l = smem_base + (unsigned)((t & 1) * STAGE_F * 4);
+        for (int s0 = wave_slot0; s0 < STAGE_SLOTS; s0 += 64 * WPB) {
+            if (s0 + lane < STAGE_SLOTS)
+                glds16(g + (size_t)(s0 + lane) * 4, __builtin_amdgcn_readfirstlane(l + (unsigned)s0 * 16));
+        }
+    };
+    // one accumulator register of a finished tile: d = c2 - 2*dot, strict '<' in ascending row order
+    auto epi_reg = [&](const f32x16 &acc, int r, const float4 &c2v) {
+        const float c2 = (r & 3) == 0 ? c2v.x : (r & 3) == 1 ? c2v.y : (r & 3) == 2 ? c2v.z : c2v.w;
+        const float dist = fmaf(-2.0f, acc[r], c2);
+        const bool lt = dist < best;
+        best = lt ? dist : best;
+        breg = lt ? r : breg;
+    };
+    // MFMAs of the tile at tb into `cur`; when have_prev, the epilogue of `prev` (tile index
+    // prev_tile) is spread over the u-steps, 16 / U registers per step
+    auto tile_pass = [&](const float *tb, f32x16 &cur, const f32x16 &prev, int prev_tile, auto have_prev) {
+        const float4 *arow = reinterpret_cast<const float4 *>(tb) + j * (R + 1) + h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cur[r] = 0.f;
+        float before = best;
+        float4 c2v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 a = arow[0];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float4 an = a;
+            if (u + 1 < U) an = arow[2 * (u + 1)];
+            cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xr[4 * u + 0], cur, 0, 0, 0);
+            cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xr[4 * u + 1], cur, 0, 0, 0);
+            cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xr[4 * u + 2], cur, 0, 0, 0);
+            cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xr[4 * u + 3], cur, 0, 0, 0);
+            if constexpr (decltype(have_prev)::value) {
+#pragma unroll
+                for (int r = (16 * u) / U; r < (16 * (u + 1)) / U; ++r) {
+                    if ((r & 3) == 0)
+                        c2v = *reinterpret_cast<const float4 *>(c2all + prev_tile * 32 + 8 * (r >> 2) + 4 * h);
+                    epi_reg(prev, r, c2v);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a = an;
+        }
+        if constexpr (decltype(have_prev)::value) btile = (best < before) ? prev_tile : btile;
+    };
+
+    f32x16 accA, accB;
+    stage(0);
+    for (int t = 0; t < n_stages; ++t) {
+        dma_wait();
+        __syncthreads();
+        if (t + 1 < n_stages) stage(t + 1);
+        const float *sb = smem + (t & 1) * STAGE_F;
+        if (t == 0)
+            tile_pass(sb, accA, accB, 0, std::false_type{});
+        else
+            tile_pass(sb, accA, accB, 2 * t - 1, std::true_type{});
+        tile_pass(sb + TILE_F, accB, accA, 2 * t, std::true_type{});
+    }
+    {   // the last tile's epilogue has nothing left to hide behind
+        const float before = best;
+        const int tile = n_tiles - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 c2v = *reinterpret_cast<const float4 *>(c2all + tile * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) epi_reg(accB, 4 * g + r, c2v);
+        }
+        btile = (best < before) ? tile : btile;
+    }
+
+    const int mine = btile * 32 + (breg & 3) + 8 * (breg >> 2) + 4 * h;
+    const float ob = __shfl_xor(best, 32);
+    const int oi = __shfl_xor(mine, 32);
+    const bool take = (ob < best) || (ob == best && oi < mine);
+    const int lab = take ? oi : mine;
+    const int64_t row = pbase + j;
+    int changed = 0;
+    if (h == 0 && row < n) {
+        const int old = labels[row];
+        labels[row] = lab;
+        changed = (old != lab);
     }
     if (n_changed != nullptr) {
 #pragma unroll

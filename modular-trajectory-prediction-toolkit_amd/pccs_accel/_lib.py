@@ -74,6 +74,10 @@ def lib():
     """Load libmtp_accel.so (once).  Raises if it has not been built -- there is no CPU path."""
     global _LIB
     if _LIB is None:
+        # torch first: its bundled HIP runtime must be the one this process initialises.  Loading
+        # libmtp_accel.so before torch pulls in /opt/rocm's libamdhip64 as a second runtime, and that
+        # one then reports "no ROCm-capable device" when torch already owns the GPU.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise MtpError(
                 f"{LIB_PATH} not found: build it with `make -C modular-trajectory-prediction-toolkit_amd/csrc` "

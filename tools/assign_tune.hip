@@ -45,6 +45,21 @@ void launch_v(const float *X, int64_t n, const float *staged, int k, int32_t *la
     CK(hipGetLastError());
 }
 
+template <int D, int WPB, int WPS, int LG = 8>
+void launch_pipe(const float *X, int64_t n, const float *staged, int k, int32_t *labels, hipStream_t s) {
+    const size_t lds = 2 * (size_t)2 * mtp_tile_floats(D) * sizeof(float) + (size_t)mtp_n_tiles(k) * 32 * sizeof(float);
+    static bool set = false;
+    if (!set) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign_mfma_pipe<D, WPB, WPS, LG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        set = true;
+    }
+    const int64_t ppb = WPB * 32;
+    hipLaunchKernelGGL((k_assign_mfma_pipe<D, WPB, WPS, LG>), dim3((unsigned)((n + ppb - 1) / ppb)), dim3(64 * WPB), lds, s, X, n,
+                       staged, mtp_n_tiles(k), labels, nullptr, nullptr, mtp_no_batch());
+    CK(hipGetLastError());
+}
+
 int main(int argc, char **argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 10000000;
     const int k = argc > 2 ? atoi(argv[2]) : 1024;
@@ -64,6 +79,10 @@ int main(int argc, char **argv) {
 
     std::vector<Variant> vs = {
         {"PT1 CTW2 WPB8 WPS4 (product)", launch_v<D, 1, 2, 8, 4, true>, true},
+        {"PIPE WPB8 WPS4", launch_pipe<D, 8, 4>, true},
+        {"PIPE WPB8 WPS4 LG16", launch_pipe<D, 8, 4, 16>, true},
+        {"PIPE WPB8 WPS3", launch_pipe<D, 8, 3>, true},
+        {"PIPE WPB4 WPS4", launch_pipe<D, 4, 4>, true},
         {"PT1 CTW2 WPB8 WPS4 LG16", launch_v<D, 1, 2, 8, 4, true, 16>, true},
         {"PT1 CTW2 WPB8 WPS4 LG4", launch_v<D, 1, 2, 8, 4, true, 4>, true},
         {"PT1 CTW2 WPB8 WPS4 PRIO", launch_v<D, 1, 2, 8, 4, true, 8, true>, true},
