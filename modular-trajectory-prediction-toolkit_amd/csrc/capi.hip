@@ -234,7 +234,14 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
 // iteration is launch-bound; 20 restarts per launch are what makes the fit fast.
 extern "C" int64_t mtp_lloyd_batched_workspace_bytes(int k, int d, int batch, int64_t n) {
     if (k <= 0 || d <= 0 || batch <= 0 || n < 0) return 0;
-    return (int64_t)(carve_lloyd(nullptr, k, d).bytes * (size_t)batch + align_up((size_t)n * 4, 256));
+    return (int64_t)(carve_lloyd(nullptr, k, d).bytes * (size_t)batch + align_up((size_t)n * 4, 256) +
+                     align_up((size_t)batch * MTP_FLAG_WORDS * 4, 256));
+}
+
+// the restarts' flag words, gathered into one contiguous block for a single plain copy to the host
+__global__ void k_collect_flags(const int32_t *flags, size_t stride_words, int batch, int32_t *out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < batch * MTP_FLAG_WORDS) out[e] = flags[(size_t)(e / MTP_FLAG_WORDS) * stride_words + e % MTP_FLAG_WORDS];
 }
 
 extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_inout, int k, int batch, int max_iter,
@@ -252,6 +259,7 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
         return MTP_E_WORKSPACE;
     }
     float *dist_scratch = reinterpret_cast<float *>(static_cast<char *>(ws) + w.bytes * (size_t)batch);
+    int32_t *flags_packed = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(dist_scratch) + align_up((size_t)n * 4, 256));
     hipStream_t s = mtp_stream(stream);
     if (check_every < 1) check_every = 1;
     MtpBatchStride bs;
@@ -275,8 +283,11 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
 
     std::vector<int32_t> hflags((size_t)batch * MTP_FLAG_WORDS);
     auto read_flags = [&]() -> int {
-        MTP_HIP(hipMemcpy2DAsync(hflags.data(), MTP_FLAG_WORDS * 4, w.flags, w.bytes, MTP_FLAG_WORDS * 4, batch,
-                                 hipMemcpyDeviceToHost, s));
+        const int words = batch * MTP_FLAG_WORDS;
+        hipLaunchKernelGGL(k_collect_flags, dim3((words + 255) / 256), dim3(256), 0, s, w.flags, w.bytes / 4, batch,
+                           flags_packed);
+        MTP_LAUNCH_CHECK();
+        MTP_HIP(hipMemcpyAsync(hflags.data(), flags_packed, (size_t)words * 4, hipMemcpyDeviceToHost, s));
         MTP_HIP(hipStreamSynchronize(s));
         return MTP_OK;
     };
