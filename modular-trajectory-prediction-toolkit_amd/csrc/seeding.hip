@@ -184,8 +184,10 @@ __global__ __launch_bounds__(256, 2) void k_kpp_dist_tile(const float *__restric
                                                        double *bsum_out0, int64_t nblk, size_t bstride, int batch) {
     constexpr int NC = 16 * CQ;      // candidate columns of the tile (8 per restart)
     constexpr int RB = 2 * CQ;       // restarts per workgroup
-    __shared__ __attribute__((aligned(16))) double ys[KPP_KC][KPP_TP + 2];
-    __shared__ __attribute__((aligned(16))) double cs[KPP_KC][NC];
+    // LDS chunks are double buffered and the next chunk's global loads are issued before this chunk's
+    // FMAs (values wait in registers): one barrier per chunk, global latency behind the arithmetic
+    __shared__ __attribute__((aligned(16))) double ys_[2][KPP_KC][KPP_TP + 2];
+    __shared__ __attribute__((aligned(16))) double cs_[2][KPP_KC][NC];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * KPP_TP;
     const int b0 = blockIdx.y * RB;
@@ -195,25 +197,55 @@ __global__ __launch_bounds__(256, 2) void k_kpp_dist_tile(const float *__restric
 #pragma unroll
         for (int q = 0; q < CQ; ++q) acc[p][q] = 0.0;
 
-    for (int kc = 0; kc < d; kc += KPP_KC) {
-        // X chunk: 128 rows x KPP_KC floats, converted once, stored feature-major
-        for (int e = tid; e < KPP_TP * (KPP_KC / 4); e += 256) {
+    constexpr int XV = KPP_TP * (KPP_KC / 4) / 256;           // float4 pieces of X per thread and chunk (2)
+    constexpr int CV = (RB * KPP_KC * 4 + 255) / 256;         // double2 pieces of the candidate tiles
+    float4 xreg[XV];
+    double2 creg[CV];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int e = tid + 256 * i;
             const int r = e / (KPP_KC / 4), q4 = e % (KPP_KC / 4);
             int64_t row = row0 + r;
             if (row >= n) row = n - 1;
-            const float4 v = *reinterpret_cast<const float4 *>(X + row * d + kc + 4 * q4);
-            ys[4 * q4 + 0][r] = (double)v.x;
-            ys[4 * q4 + 1][r] = (double)v.y;
-            ys[4 * q4 + 2][r] = (double)v.z;
-            ys[4 * q4 + 3][r] = (double)v.w;
+            xreg[i] = *reinterpret_cast<const float4 *>(X + row * d + kc + 4 * q4);
         }
-        // candidate chunk: restart rb's rows kc..kc+KPP_KC-1 are KPP_KC x 8 contiguous doubles (feature-major)
-        for (int e = tid; e < RB * KPP_KC * 8; e += 256) {
-            const int rb = e / (KPP_KC * 8), w = e % (KPP_KC * 8);
+#pragma unroll
+        for (int i = 0; i < CV; ++i) {
+            const int e = tid + 256 * i;  // double2 index: restart rb, pair w2 of its KPP_KC x 8 chunk
+            const int rb = e / (KPP_KC * 4), w2 = e % (KPP_KC * 4);
             const int b = b0 + rb;
-            cs[w >> 3][rb * 8 + (w & 7)] = b < batch ? kpp_at(cand_x0, bstride, b)[(size_t)kc * 8 + w] : 0.0;
+            creg[i] = make_double2(0.0, 0.0);
+            if (e < RB * KPP_KC * 4 && b < batch)
+                creg[i] = *reinterpret_cast<const double2 *>(kpp_at(cand_x0, bstride, b) + (size_t)kc * 8 + 2 * w2);
         }
-        __syncthreads();
+    };
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int e = tid + 256 * i;
+            const int r = e / (KPP_KC / 4), q4 = e % (KPP_KC / 4);
+            ys_[buf][4 * q4 + 0][r] = (double)xreg[i].x;
+            ys_[buf][4 * q4 + 1][r] = (double)xreg[i].y;
+            ys_[buf][4 * q4 + 2][r] = (double)xreg[i].z;
+            ys_[buf][4 * q4 + 3][r] = (double)xreg[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < CV; ++i) {
+            const int e = tid + 256 * i;
+            const int rb = e / (KPP_KC * 4), w2 = e % (KPP_KC * 4);
+            if (e < RB * KPP_KC * 4)
+                *reinterpret_cast<double2 *>(&cs_[buf][w2 >> 2][rb * 8 + 2 * (w2 & 3)]) = creg[i];
+        }
+    };
+
+    fetch(0);
+    for (int kc = 0, buf = 0; kc < d; kc += KPP_KC, buf ^= 1) {
+        deposit(buf);
+        __syncthreads();  // chunk visible; every thread is past the FMAs that read the other buffer
+        if (kc + KPP_KC < d) fetch(kc + KPP_KC);
+        const double (*ys)[KPP_TP + 2] = ys_[buf];
+        const double (*cs)[NC] = cs_[buf];
         // operands of step kk+1 are read from LDS while the 8*CQ multiply-adds of step kk issue
         double yv[8], cv[CQ];
 #pragma unroll
@@ -242,7 +274,6 @@ __global__ __launch_bounds__(256, 2) void k_kpp_dist_tile(const float *__restric
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
     }
 
     // epilogue: distance, clamp, min with the closest-so-far row, store, block sums.  All loads
