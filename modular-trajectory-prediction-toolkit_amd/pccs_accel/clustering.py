@@ -82,6 +82,8 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
     n, d = X.shape
     if n < n_clusters:
         raise ValueError(f"n_samples={n} should be >= n_clusters={n_clusters}.")
+    if not bool(torch.isfinite(X).all()):  # sklearn's check_array (cluster/_kmeans.py:1463) refuses these too
+        raise ValueError("Input X contains NaN or infinity.")
     if random_state is None:
         rs = np.random.mtrand._rand
     elif isinstance(random_state, (int, np.integer)):

@@ -401,3 +401,13 @@ def test_get_memory_data_writes_reference_files(tmp_path, gpu_device):
     np.random.seed(1)
     ol, osz = O.cluster_data(X.copy(), 10)
     assert _same_partition(labels, ol) and np.array_equal(np.sort(sizes), np.sort(osz))
+
+
+def test_kmeans_fit_rejects_non_finite_input_like_sklearn(gpu_device):
+    from pccs_accel.clustering import kmeans_fit
+    X = dev(datagen.make_encodings(5, 300, 96, 4), gpu_device)
+    X[17, 3] = float("nan")
+    with pytest.raises(ValueError, match="NaN"):
+        kmeans_fit(X, 4, n_init=1)
+    with pytest.raises(ValueError, match="should be >= n_clusters"):
+        kmeans_fit(X[:3].contiguous(), 4, n_init=1)
