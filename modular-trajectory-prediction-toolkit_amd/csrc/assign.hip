@@ -116,7 +116,7 @@ static int launch_assign_mfma(const float *X, int64_t n, const float *staged, in
     const int64_t blocks = (n + pts_per_block - 1) / pts_per_block;
     MTP_REQUIRE(blocks <= 0x7fffffff, "mtp_assign: n too large");
     hipLaunchKernelGGL((k_assign_mfma<D, PT, CTW, WPB, WPS, true>), dim3((unsigned)blocks, bs.batch), dim3(64 * WPB), lds, s, X, n,
-                       staged, mtp_n_tiles(k), labels, n_changed, state, bs);
+                       staged, (k + 31) / 32, labels, n_changed, state, bs);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }

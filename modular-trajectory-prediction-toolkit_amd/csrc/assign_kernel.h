@@ -48,6 +48,8 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
                                                         const float *__restrict__ staged, int n_tiles,
                                                         int32_t *__restrict__ labels, double *n_changed,
                                                         const int32_t *state, MtpBatchStride bs) {
+    // n_tiles: tiles that hold centroids (ceil(k / 32)); the image is padded to whole stages, and
+    // the tiles of the last stage beyond n_tiles are skipped
     constexpr int R = D / 4;                 // 16-byte slots per centroid row
     constexpr int TILE_F = 32 * (D + 4) + 32;  // floats per 32-centroid tile image (rows padded by one slot)
     constexpr int STAGE_F = CTW * TILE_F;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
         btile[pt] = 0;
     }
 
-    const int n_stages = n_tiles / CTW;
+    const int n_stages = (n_tiles + CTW - 1) / CTW;
     const int wave_slot0 = wave * 64;
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     auto stage = [&](int t) {
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
         const float *sb = smem + (t & 1) * STAGE_F;
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct) {
+            if (CTW > 1 && t * CTW + ct >= n_tiles) break;  // padding tile of the last stage (uniform)
             const float *tb = sb + ct * TILE_F;
             const float4 *arow = reinterpret_cast<const float4 *>(tb) + j * (R + 1) + h;
             f32x16 acc[PT];

@@ -41,7 +41,7 @@ void launch_v(const float *X, int64_t n, const float *staged, int k, int32_t *la
     }
     const int64_t ppb = WPB * 32 * PT;
     hipLaunchKernelGGL((k_assign_mfma<D, PT, CTW, WPB, WPS, EPI, LG, PRIO>), dim3((unsigned)((n + ppb - 1) / ppb)), dim3(64 * WPB), lds, s, X,
-                       n, staged, mtp_n_tiles(k), labels, nullptr, nullptr, mtp_no_batch());
+                       n, staged, (k + 31) / 32, labels, nullptr, nullptr, mtp_no_batch());
     CK(hipGetLastError());
 }
 
