@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--eval-n", type=int, default=1_000_000)
     ap.add_argument("--eval-k", type=int, default=100)
     ap.add_argument("--eval-t", type=int, default=12)
-    ap.add_argument("--cpu-sample", type=int, default=5_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
