@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo); not a valid scaling result")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="rehearsal only: with one rank (launched through torch.distributed.run), create the RCCL "
+                         "communicator anyway and issue every collective of the N > 1 path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,7 +152,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collectives
+    if collective:
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
@@ -159,7 +163,7 @@ def main():
     from pccs_accel import kernels as K
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -179,19 +183,19 @@ def main():
     # fixed init: K rows of rank 0's shard, the same on every rank
     perm = torch.randperm(min(n_local, 1 << 22), generator=torch.Generator().manual_seed(3))[:k].to(device)
     C0 = X[perm].contiguous()
-    if world > 1:  # rank 0's rows everywhere (a sum with zeros: one code path for RCCL and gloo)
+    if collective:  # rank 0's rows everywhere (a sum with zeros: one code path for RCCL and gloo)
         if rank != 0:
             C0.zero_()
         allreduce(C0)
     # centring as KMeans.fit does (global mean)
     col = K.col_sums(X)
-    if world > 1:
+    if collective:
         allreduce(col)
     mean32 = (col / n).to(torch.float32)
     K.sub_rowvec_(X, mean32)
     K.sub_rowvec_(C0, mean32)
 
-    sl = pdist.ShardedLloyd(X, C0, row_offset=lo)
+    sl = pdist.ShardedLloyd(X, C0, row_offset=lo, force_collectives=args.force_collectives)
     TOL_NEVER = -1.0            # shift_tot <= tol never holds: no early exit inside the timed region
     MAX_IT = 1 << 30
     total_steps = args.warmup + args.steps
@@ -221,7 +225,7 @@ def main():
         n_relocated += sl.finish_step(TOL_NEVER, MAX_IT)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         allreduce(tmax, dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -255,9 +259,10 @@ def main():
         "value": evals_per_s, "unit": "distance-evals/s (N*K*D MACs of the cross term per second, whole job)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic" + (" (REHEARSAL: all ranks on one device, not a scaling result)" if args.one_device else ""),
+        "data": "synthetic" + (" (REHEARSAL: all ranks on one device, not a scaling result)" if args.one_device else "")
+                + (" (REHEARSAL: one-rank RCCL communicator, collectives forced)" if args.force_collectives and world == 1 else ""),
         "config": {"workload": f"k-means Lloyd iterations, synthetic encodings N={n} D={d} K={k}, fixed init, "
-                               f"points sharded over {world} GPU(s)" + (", RCCL all-reduce of sums/counts" if world > 1 else ""),
+                               f"points sharded over {world} GPU(s)" + (", RCCL all-reduce of sums/counts" if collective else ""),
                    "n": n, "d": d, "k": k, "parallelism": f"points/{world}"},
         "iters_per_s": args.steps / dt, "clusters_relocated": n_relocated,
         "ms_breakdown": {"assign": ms_assign, "accumulate": ms_accum, "allreduce+mstep": ms_rest},
@@ -279,11 +284,11 @@ def main():
         for i in range(reps):
             r = K.best_of_k(pred, gt, mode=i % 3)
         e1.record()
-        if world > 1:
+        if collective:
             allreduce(r["sums"])
         barrier()
         edt = time.perf_counter() - t0
-        if world > 1:
+        if collective:
             tmax = torch.tensor([edt], dtype=torch.float64, device=device)
             allreduce(tmax, dist.ReduceOp.MAX)
             edt = float(tmax.item())
@@ -318,7 +323,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

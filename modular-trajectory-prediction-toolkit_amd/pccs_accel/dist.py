@@ -126,12 +126,15 @@ class ShardedLloyd:
     identical on every rank.  ``row_offset``: global index of the first local row.
     """
 
-    def __init__(self, X_local, C0, row_offset=0, group=None, ops=None):
+    def __init__(self, X_local, C0, row_offset=0, group=None, ops=None, force_collectives=False):
+        # force_collectives: issue every collective even at world_size 1 (a one-rank RCCL
+        # communicator), so that the RCCL code path can be exercised on a one-GPU box
         self.X = X_local
         self.n, self.d = X_local.shape
         self.k = C0.shape[0]
         self.group = group
         self.rank, self.world = world()
+        self.collective = self.world > 1 or (force_collectives and dist.is_initialized())
         self.row_offset = row_offset
         self.ops = ops if ops is not None else DeviceOps(X_local.device)
         o = self.ops
@@ -156,7 +159,7 @@ class ShardedLloyd:
         self.ops.accumulate(self.X, self.k, self.labels, self.red, self.flags)
 
     def reduce(self):
-        if self.world > 1:
+        if self.collective:
             all_reduce_sum(self.red, self.group)
 
     def mstep(self, tol, max_iter, relocation_done=0):
@@ -193,7 +196,7 @@ class ShardedLloyd:
         m = min(int(m), MAX_RELOC)
         self.red.copy_(self.red_backup)  # the paused M-step parked the reduced buffer there
         val, idx, lab, rows = o.far_points(self.X, self.cbuf[old], self.labels, m, self.row_offset)
-        if self.world > 1:
+        if self.collective:
             gv = all_gather_cat(val, self.world, self.group)
             gi = all_gather_cat(idx, self.world, self.group)
             gl = all_gather_cat(lab, self.world, self.group)
@@ -243,23 +246,24 @@ class ShardedLloyd:
         if f[FLAG_STATE] != STATE_STRICT:
             self.ops.final_assign(self.X, centers, self.staged, self.c2, self.k, self.labels)
         inertia = self.ops.inertia(self.X, centers, self.labels)
-        if self.world > 1:
+        if self.collective:
             all_reduce_sum(inertia, self.group)
         return self.labels, float(inertia.item()), centers, n_iter
 
 
-def kmeans_fit_sharded(X_local, n_total, C0, row_offset, tol=1e-4, max_iter=300, check_every=1, group=None):
+def kmeans_fit_sharded(X_local, n_total, C0, row_offset, tol=1e-4, max_iter=300, check_every=1, group=None,
+                       force_collectives=False):
     """KMeans(init=C0, n_init=1).fit over row-sharded, un-centred points: global mean / tolerance
     by all-reduce of column sums, then ShardedLloyd.  C0 (un-centred) identical on every rank."""
     from . import kernels as K
     rank, ws = world()
-    d = X_local.shape[1]
+    collective = ws > 1 or (force_collectives and dist.is_initialized())
     col_sum = K.col_sums(X_local)
-    if ws > 1:
+    if collective:
         all_reduce_sum(col_sum, group)
     mean64 = col_sum / n_total
     sqdev = K.col_sqdev(X_local, mean64)
-    if ws > 1:
+    if collective:
         all_reduce_sum(sqdev, group)
     tol_abs = float((sqdev / n_total).mean().item()) * tol if tol != 0 else 0.0
     mean32 = mean64.to(torch.float32)
@@ -267,6 +271,6 @@ def kmeans_fit_sharded(X_local, n_total, C0, row_offset, tol=1e-4, max_iter=300,
     K.sub_rowvec_(Xc, mean32)
     C0c = C0.clone().contiguous()
     K.sub_rowvec_(C0c, mean32)
-    sl = ShardedLloyd(Xc, C0c, row_offset=row_offset, group=group)
+    sl = ShardedLloyd(Xc, C0c, row_offset=row_offset, group=group, force_collectives=force_collectives)
     labels, inertia, centers, n_iter = sl.run(max_iter=max_iter, tol_abs=tol_abs, check_every=check_every)
     return dict(labels=labels, centers=centers + mean32, inertia=inertia, n_iter=n_iter, tol_abs=tol_abs)

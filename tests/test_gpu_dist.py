@@ -77,3 +77,39 @@ def test_sharded_device_lloyd_matches_single(which, world, check_every, tmp_path
     assert np.array_equal(labels, single["labels"].cpu().numpy())
     assert np.allclose(parts[0]["centers"], single["centers"].cpu().numpy(), rtol=1e-6, atol=1e-7)
     assert np.isclose(float(parts[0]["inertia"]), single["inertia"], rtol=1e-9)
+
+
+def _rccl_worker(rank, port, which, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)
+    sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "tests", "golden")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from pccs_accel import dist as pdist
+    X, C0 = _case(which)
+    fit = pdist.kmeans_fit_sharded(torch.from_numpy(X).to(dev), X.shape[0], torch.from_numpy(C0).to(dev),
+                                   row_offset=0, check_every=2, force_collectives=True)
+    np.savez(os.path.join(out_dir, "rccl.npz"), labels=fit["labels"].cpu().numpy(),
+             centers=fit["centers"].cpu().numpy(), inertia=fit["inertia"], n_iter=fit["n_iter"])
+    dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+
+
+@pytest.mark.parametrize("which", ["plain", "relocate"])
+def test_rccl_one_rank_collectives(which, tmp_path, gpu_device):
+    """The RCCL ("nccl") backend itself: a one-rank communicator on the box's one GPU, every
+    collective of the sharded driver issued on the device buffers (fp64 all-reduce of the packed
+    sums, the relocation all-gathers, the inertia all-reduce).  Same answer as the plain run."""
+    from pccs_accel import clustering
+    mp.spawn(_rccl_worker, args=(_free_port(), which, str(tmp_path)), nprocs=1, join=True)
+    X, C0 = _case(which)
+    single = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), C0.shape[0], init=torch.from_numpy(C0))
+    p = np.load(tmp_path / "rccl.npz")
+    assert int(p["n_iter"]) == single["n_iter"]
+    assert np.array_equal(p["labels"], single["labels"].cpu().numpy())
+    assert np.allclose(p["centers"], single["centers"].cpu().numpy(), rtol=1e-6, atol=1e-7)
+    assert np.isclose(float(p["inertia"]), single["inertia"], rtol=1e-9)
