@@ -172,11 +172,13 @@ __global__ __launch_bounds__(64) void k_mstep_centers(double *red, const float *
     if (staged != nullptr) mtp_write_staged_row(staged, j, d, rn, valid, valid ? c2s : 0.f, threadIdx.x, 64);
 }
 
-__global__ __launch_bounds__(256) void k_mstep_flags(double *red, int k, int d, double tol, int max_iter,
-                                                     int relocation_done, const float *shift, int32_t *flags,
-                                                     double *red_backup, MtpBatchStride bs) {
-    __shared__ int scratch[4];
-    __shared__ double dsum[4];
+// One 1024-thread block per restart: the decision needs every count and shift, and the block then
+// zeroes the reduce buffer for the next iteration (1 MB at K=1024, D=128: 16 waves of 512-byte stores).
+__global__ __launch_bounds__(1024) void k_mstep_flags(double *red, int k, int d, double tol, int max_iter,
+                                                      int relocation_done, const float *shift, int32_t *flags,
+                                                      double *red_backup, MtpBatchStride bs) {
+    __shared__ int scratch[16];
+    __shared__ double dsum[16];
     {
         const size_t b = blockIdx.x;
         red += b * bs.red;
@@ -215,7 +217,8 @@ __global__ __launch_bounds__(256) void k_mstep_flags(double *red, int k, int d, 
     const int64_t len = mtp_red_len(k, d);
     for (int64_t e = threadIdx.x; e < len; e += blockDim.x) red[e] = 0.0;
     if (threadIdx.x == 0) {
-        const double tot = dsum[0] + dsum[1] + dsum[2] + dsum[3];
+        double tot = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += dsum[w];
         const int it = flags[MTP_FLAG_N_ITER] + 1;
         flags[MTP_FLAG_N_ITER] = it;
         flags[MTP_FLAG_N_EMPTY] = 0;
@@ -239,7 +242,7 @@ int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d
     hipLaunchKernelGGL(k_mstep_centers, dim3(rows, bs.batch), dim3(64), 2 * (size_t)d * sizeof(float), s, red, C_old,
                        C_new, k, d, relocation_done, mfma ? staged : nullptr, c2, shift, flags, bs, flag_parity);
     MTP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_mstep_flags, dim3(bs.batch), dim3(256), 0, s, red, k, d, tol, max_iter, relocation_done, shift,
+    hipLaunchKernelGGL(k_mstep_flags, dim3(bs.batch), dim3(1024), 0, s, red, k, d, tol, max_iter, relocation_done, shift,
                        flags, red_backup, bs);
     MTP_LAUNCH_CHECK();
     return MTP_OK;

@@ -68,6 +68,8 @@ class DeviceOps:
 
     def __init__(self, device):
         self.device = device
+        self._ring = None
+        self._ring_pos = 0
 
     def zeros(self, n, dtype):
         return torch.zeros(n, dtype=dtype, device=self.device)
@@ -117,6 +119,23 @@ class DeviceOps:
     def inertia(self, X, C, labels):
         from . import kernels as K
         return K.inertia(X, C, labels)
+
+    def snapshot(self, flags):
+        """Asynchronous copy of the flag words to pinned host memory, in stream order behind the
+        kernels enqueued so far; ``wait`` returns them without holding up later launches."""
+        if self._ring is None:  # at most two snapshots are alive at a time (the lag is one step)
+            self._ring = [(torch.empty(FLAG_WORDS, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+                          for _ in range(4)]
+        host, ev = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        host.copy_(flags, non_blocking=True)
+        ev.record()
+        return host, ev
+
+    def wait(self, snap):
+        host, ev = snap
+        ev.synchronize()
+        return host.numpy().copy()
 
 
 class ShardedLloyd:
@@ -190,6 +209,68 @@ class ShardedLloyd:
         self.cur ^= 1
         return n_reloc
 
+    def run_fixed(self, n_steps, tol, max_iter, on_phase=None):
+        """``n_steps`` further iterations with the flags read ONE STEP LATE: the snapshot of
+        iteration i is looked at after iteration i+1 has been enqueued, so the device never waits
+        for the host.  When iteration i paused on an empty cluster, the kernels of the attempt
+        enqueued behind it were no-ops (state != RUNNING; its all-reduce added zeros to the parked
+        buffer): the relocation and the M-step are redone and that attempt is enqueued again.
+        ``on_phase(attempt, phase)`` (phase 0..3 = before assign / accumulate / reduce+mstep /
+        after) lets bench.py bracket the kernels with events.  Returns (clusters relocated,
+        attempts that were no-ops, attempts made, final state word); stops early only when the
+        loop converged."""
+        start = int(self.read_flags()[FLAG_N_ITER])
+        target = start + n_steps
+        enq = start          # iterations done once everything enqueued so far has run
+        attempt = 0
+        noop = []
+        pending = None       # snapshot taken behind the previous attempt
+        n_reloc = 0
+        state = STATE_RUNNING
+        cb = on_phase if on_phase is not None else (lambda a, ph: None)
+        while True:
+            snap = None
+            this_attempt = None
+            if enq < target and state == STATE_RUNNING:
+                this_attempt = attempt
+                cb(attempt, 0)
+                self.assign()
+                cb(attempt, 1)
+                self.accumulate()
+                cb(attempt, 2)
+                self.reduce()
+                self.mstep(tol, max_iter)
+                cb(attempt, 3)
+                self.cur ^= 1
+                enq += 1
+                attempt += 1
+                snap = self.ops.snapshot(self.flags)
+            if pending is not None:
+                f = self.ops.wait(pending)
+                state = int(f[FLAG_STATE])
+                if state == STATE_RELOCATE:
+                    done = int(f[FLAG_N_ITER])
+                    old = done & 1
+                    n_reloc += int(f[FLAG_N_EMPTY])
+                    self._relocate(f[FLAG_N_EMPTY], old)
+                    self.flags[FLAG_STATE] = STATE_RUNNING
+                    self.cur = old
+                    self.mstep(tol, max_iter, relocation_done=1)
+                    self.cur = old ^ 1
+                    enq = done + 1
+                    if this_attempt is not None:
+                        noop.append(this_attempt)  # ran behind the pause; its snapshot is stale
+                    state = STATE_RUNNING
+                    # the redone M-step may itself end the loop (max_iter / convergence)
+                    pending = self.ops.snapshot(self.flags)
+                    continue
+                if state != STATE_RUNNING and this_attempt is not None:
+                    noop.append(this_attempt)  # enqueued behind the iteration that ended the loop
+            pending = snap
+            if pending is None:
+                break
+        return n_reloc, noop, attempt, state
+
     def _relocate(self, m, old):
         """Global top-m farthest points -> apply to the (replicated) reduced buffer."""
         o = self.ops
@@ -252,7 +333,7 @@ class ShardedLloyd:
 
 
 def kmeans_fit_sharded(X_local, n_total, C0, row_offset, tol=1e-4, max_iter=300, check_every=1, group=None,
-                       force_collectives=False):
+                       force_collectives=False, lagged_steps=0):
     """KMeans(init=C0, n_init=1).fit over row-sharded, un-centred points: global mean / tolerance
     by all-reduce of column sums, then ShardedLloyd.  C0 (un-centred) identical on every rank."""
     from . import kernels as K
@@ -272,5 +353,7 @@ def kmeans_fit_sharded(X_local, n_total, C0, row_offset, tol=1e-4, max_iter=300,
     C0c = C0.clone().contiguous()
     K.sub_rowvec_(C0c, mean32)
     sl = ShardedLloyd(Xc, C0c, row_offset=row_offset, group=group, force_collectives=force_collectives)
+    if lagged_steps:  # the first iterations with the flags read one step late (ShardedLloyd.run_fixed)
+        sl.run_fixed(min(lagged_steps, max_iter), tol_abs, max_iter)
     labels, inertia, centers, n_iter = sl.run(max_iter=max_iter, tol_abs=tol_abs, check_every=check_every)
     return dict(labels=labels, centers=centers + mean32, inertia=inertia, n_iter=n_iter, tol_abs=tol_abs)

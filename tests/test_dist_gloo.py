@@ -114,6 +114,12 @@ class NumpyOps:
         if X.shape[0]:
             labels.copy_(torch.from_numpy(O.assign(X.numpy(), C.numpy(), c2.numpy())))
 
+    def snapshot(self, flags):
+        return flags.clone()
+
+    def wait(self, snap):
+        return snap.numpy()
+
     def inertia(self, X, C, labels):
         v = O.inertia(X.numpy(), C.numpy(), labels.numpy()) if X.shape[0] else 0.0
         return torch.tensor([v], dtype=torch.float64)
@@ -133,7 +139,7 @@ def _case(which):
     return Xc, C0, float(O.tolerance(X))
 
 
-def _worker(rank, world, port, which, check_every, out_dir):
+def _worker(rank, world, port, which, check_every, out_dir, fixed_steps=0):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -143,9 +149,14 @@ def _worker(rank, world, port, which, check_every, out_dir):
     lo, hi = pdist.shard_bounds(Xc.shape[0], rank, world)
     sl = pdist.ShardedLloyd(torch.from_numpy(Xc[lo:hi].copy()), torch.from_numpy(C0.copy()), row_offset=lo,
                             ops=NumpyOps())
+    extra = {}
+    if fixed_steps:  # the first iterations with the flags read one step late (what bench.py times)
+        n_reloc, noop, attempts, state = sl.run_fixed(fixed_steps, tol, 300)
+        extra = dict(n_reloc=n_reloc, n_noop=len(noop), attempts=attempts, state=state,
+                     iters_after_fixed=int(sl.read_flags()[1]))
     labels, inertia, centers, n_iter = sl.run(max_iter=300, tol_abs=tol, check_every=check_every)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), labels=labels.numpy(), centers=centers.numpy(), inertia=inertia,
-             n_iter=n_iter, lo=lo, hi=hi)
+             n_iter=n_iter, lo=lo, hi=hi, **extra)
     dist.destroy_process_group()
 
 
@@ -170,6 +181,32 @@ def test_sharded_lloyd_matches_oracle(which, world, check_every, tmp_path):
         assert int(p["n_iter"]) == on
         assert np.array_equal(p["centers"], parts[0]["centers"])
         assert float(p["inertia"]) == float(parts[0]["inertia"])
+    assert np.array_equal(labels, ol)
+    assert np.allclose(parts[0]["centers"], oc, rtol=1e-5, atol=1e-6)
+    assert np.isclose(float(parts[0]["inertia"]), oi, rtol=1e-6)
+
+
+@pytest.mark.parametrize("which", ["plain", "relocate"])
+@pytest.mark.parametrize("world,fixed_steps", [(1, 3), (2, 3), (2, 1000), (3, 1)])
+def test_lagged_flag_checks_match_oracle(which, world, fixed_steps, tmp_path):
+    """run_fixed (flags looked at one step late, paused / finished attempts re-enqueued or dropped)
+    followed by run() must land on the oracle's result, whether the fixed part ends mid-run (3),
+    right behind the relocation pause (1) or runs into convergence (1000)."""
+    mp.spawn(_worker, args=(world, _free_port(), which, 1, str(tmp_path), fixed_steps), nprocs=world, join=True)
+    Xc, C0, tol = _case(which)
+    ol, oi, oc, on = O.kmeans_single_lloyd(Xc, C0, 300, tol)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    labels = np.concatenate([p["labels"] for p in parts])
+    for p in parts:
+        assert int(p["n_iter"]) == on
+        assert np.array_equal(p["centers"], parts[0]["centers"])
+        assert int(p["iters_after_fixed"]) == min(fixed_steps, on)
+        # every attempt is either an iteration or a recorded no-op
+        assert int(p["attempts"]) - int(p["n_noop"]) == min(fixed_steps, on)
+        if fixed_steps < on:
+            assert int(p["state"]) == 0
+        if which == "relocate":
+            assert int(p["n_reloc"]) >= 1
     assert np.array_equal(labels, ol)
     assert np.allclose(parts[0]["centers"], oc, rtol=1e-5, atol=1e-6)
     assert np.isclose(float(parts[0]["inertia"]), oi, rtol=1e-6)

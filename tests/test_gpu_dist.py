@@ -33,7 +33,7 @@ def _case(which):
     return X, C0
 
 
-def _worker(rank, world, port, which, check_every, out_dir):
+def _worker(rank, world, port, which, check_every, out_dir, lagged_steps=0):
     import faulthandler
     faulthandler.dump_traceback_later(60, exit=True)  # a stuck rank names its line and ends the test
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
@@ -46,7 +46,7 @@ def _worker(rank, world, port, which, check_every, out_dir):
     dev = torch.device("cuda:0")
     lo, hi = pdist.shard_bounds(X.shape[0], rank, world)
     fit = pdist.kmeans_fit_sharded(torch.from_numpy(X[lo:hi].copy()).to(dev), X.shape[0], torch.from_numpy(C0).to(dev),
-                                   row_offset=lo, check_every=check_every)
+                                   row_offset=lo, check_every=check_every, lagged_steps=lagged_steps)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), labels=fit["labels"].cpu().numpy(),
              centers=fit["centers"].cpu().numpy(), inertia=fit["inertia"], n_iter=fit["n_iter"], lo=lo, hi=hi)
     dist.destroy_process_group()
@@ -62,10 +62,12 @@ def _free_port():
 
 
 @pytest.mark.parametrize("which", ["plain", "relocate"])
-@pytest.mark.parametrize("world,check_every", [(2, 1), (3, 4)])
-def test_sharded_device_lloyd_matches_single(which, world, check_every, tmp_path, gpu_device):
+@pytest.mark.parametrize("world,check_every,lagged", [(2, 1, 0), (3, 4, 0), (2, 1, 5), (1, 1, 1000)])
+def test_sharded_device_lloyd_matches_single(which, world, check_every, lagged, tmp_path, gpu_device):
+    """lagged > 0: the first iterations go through run_fixed (flags read one step late through
+    pinned snapshots, what bench.py times); 1000 runs it into convergence."""
     from pccs_accel import clustering
-    mp.spawn(_worker, args=(world, _free_port(), which, check_every, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), which, check_every, str(tmp_path), lagged), nprocs=world, join=True)
     X, C0 = _case(which)
     single = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), C0.shape[0], init=torch.from_numpy(C0))
     parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
@@ -92,7 +94,7 @@ def _rccl_worker(rank, port, which, out_dir):
     from pccs_accel import dist as pdist
     X, C0 = _case(which)
     fit = pdist.kmeans_fit_sharded(torch.from_numpy(X).to(dev), X.shape[0], torch.from_numpy(C0).to(dev),
-                                   row_offset=0, check_every=2, force_collectives=True)
+                                   row_offset=0, check_every=2, force_collectives=True, lagged_steps=4)
     np.savez(os.path.join(out_dir, "rccl.npz"), labels=fit["labels"].cpu().numpy(),
              centers=fit["centers"].cpu().numpy(), inertia=fit["inertia"], n_iter=fit["n_iter"])
     dist.destroy_process_group()
