@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--n", "--points", dest="n", type=int, default=10_000_000)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--k", type=int, default=1024)
     ap.add_argument("--eval-n", type=int, default=1_000_000)

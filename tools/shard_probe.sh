@@ -5,5 +5,5 @@ set -u
 OUT=gpurun_out
 mkdir -p $OUT
 timeout -k 10 200 python bench.py --n 1250000 --steps 30 --warmup 3 --no-eval --no-cpu > $OUT/shard_plain.json 2> $OUT/shard_plain.err || { tail -20 $OUT/shard_plain.err; exit 1; }
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --n 1250000 --steps 30 --warmup 3 --no-eval --no-cpu --force-collectives > $OUT/shard_rccl.json 2> $OUT/shard_rccl.err || { tail -20 $OUT/shard_rccl.err; exit 1; }
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --points 1250000 --steps 30 --warmup 3 --no-eval --no-cpu --force-collectives > $OUT/shard_rccl.json 2> $OUT/shard_rccl.err || { tail -20 $OUT/shard_rccl.err; exit 1; }
 echo PROBE_OK
