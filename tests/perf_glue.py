@@ -2,7 +2,8 @@
 """Timing of the SURVEY.md 8(f) kernels (decode glue, NMS re-ranking, scene soft labels) at sizes
 that fill the GPU, each with its algorithmic bytes / pair tests and the CPU oracle timed on a
 bounded sample beside it.  Development measurement: one JSON object per kernel on stdout; the
-numbers go to DESIGN.md.  (bench.py stays the headline line.)"""
+numbers go to DESIGN.md.  (bench.py stays the headline line.)  Lives under tests/ because it times the CPU
+oracle beside the kernels, and the oracle is test infrastructure only; pytest does not collect it."""
 import json
 import os
 import sys
