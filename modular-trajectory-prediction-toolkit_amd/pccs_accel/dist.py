@@ -357,3 +357,25 @@ def kmeans_fit_sharded(X_local, n_total, C0, row_offset, tol=1e-4, max_iter=300,
         sl.run_fixed(min(lagged_steps, max_iter), tol_abs, max_iter)
     labels, inertia, centers, n_iter = sl.run(max_iter=max_iter, tol_abs=tol_abs, check_every=check_every)
     return dict(labels=labels, centers=centers + mean32, inertia=inertia, n_iter=n_iter, tol_abs=tol_abs)
+
+
+def best_of_k_sharded(pred_local, gt_local, n_total, mode=0, ade_div=None, best_of=None, group=None,
+                      force_collectives=False, kernel=None):
+    """Best-of-K ADE/FDE (PCCSNet/train_steps.py:214-233, StimulusVerification/verify_predictions.py:238-248)
+    with the agents sharded over the ranks: every rank scores its own agents (no exchange), then ONE
+    all-reduce of the two double sums gives the mean over all ``n_total`` agents on every rank.
+
+    Returns the local per-agent results of ``kernels.best_of_k`` plus ``mean_ade`` / ``mean_fde``
+    (Python floats, global).  ``kernel``: test hook, a stand-in for ``kernels.best_of_k``."""
+    if kernel is None:
+        from . import kernels as K
+        kernel = K.best_of_k
+    rank, ws = world()
+    r = kernel(pred_local, gt_local, mode=mode, ade_div=ade_div, best_of=best_of)
+    sums = r["sums"]
+    if ws > 1 or (force_collectives and dist.is_initialized()):
+        all_reduce_sum(sums, group)
+    total = sums.cpu()
+    r["mean_ade"] = float(total[0]) / n_total
+    r["mean_fde"] = float(total[1]) / n_total
+    return r

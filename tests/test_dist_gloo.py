@@ -212,6 +212,51 @@ def test_lagged_flag_checks_match_oracle(which, world, fixed_steps, tmp_path):
     assert np.isclose(float(parts[0]["inertia"]), oi, rtol=1e-6)
 
 
+def _eval_worker(rank, world, port, out_dir):
+    sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pccs_accel import dist as pdist
+    pred, gt = _eval_case()
+    lo, hi = pdist.shard_bounds(pred.shape[0], rank, world)
+
+    def cpu_kernel(p, g, mode=0, ade_div=None, best_of=None):  # the oracle in the kernel's place
+        o = O.best_of_k(p.numpy(), g.numpy(), mode, ade_div=ade_div, best_of=best_of)
+        return dict(min_ade=torch.from_numpy(o["min_ade"]), min_fde=torch.from_numpy(o["min_fde"]),
+                    idx=torch.from_numpy(o["idx"]), sums=torch.tensor([o["sum_ade"], o["sum_fde"]], dtype=torch.float64))
+
+    out = {}
+    for mode in (0, 1, 2):
+        r = pdist.best_of_k_sharded(torch.from_numpy(pred[lo:hi].copy()), torch.from_numpy(gt[lo:hi].copy()),
+                                    pred.shape[0], mode=mode, kernel=cpu_kernel)
+        out[f"mean{mode}"] = np.array([r["mean_ade"], r["mean_fde"]])
+        out[f"idx{mode}"] = r["idx"].numpy()
+    np.savez(os.path.join(out_dir, f"e{rank}.npz"), **out)
+    dist.destroy_process_group()
+
+
+def _eval_case():
+    rng = np.random.default_rng(5)
+    gt = np.cumsum(rng.normal(0, 0.3, (101, 12, 2)), axis=1).astype(np.float32)
+    pred = (gt[:, None] + rng.normal(0, 0.2, (101, 20, 12, 2))).astype(np.float32)
+    return pred, gt
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_best_of_k_sharded_means(world, tmp_path):
+    """Agents sharded, one all-reduce of the two sums: every rank reports the global means."""
+    mp.spawn(_eval_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    pred, gt = _eval_case()
+    parts = [np.load(tmp_path / f"e{r}.npz") for r in range(world)]
+    for mode in (0, 1, 2):
+        o = O.best_of_k(pred, gt, mode)
+        want = np.array([o["mean_ade"], o["mean_fde"]])
+        for p in parts:
+            assert np.allclose(p[f"mean{mode}"], want, rtol=1e-12)
+        assert np.array_equal(np.concatenate([p[f"idx{mode}"] for p in parts]), o["idx"])
+
+
 def test_shard_bounds_cover_everything():
     sys.path.insert(0, PKG_DIR)
     from pccs_accel.dist import shard_bounds
