@@ -15,6 +15,9 @@
 //                                input is upcast, stored back as float32, clamped), min with the
 //                                closest-so-far, per-block double sums (the potentials)
 // np.cumsum / the BLAS sums are replaced by double tree sums: differences ~1e-16 relative.
+#include <cstdlib>
+#include <cstring>
+
 #include "mtp_internal.h"
 
 static constexpr int KPP_PB = 256;     // points per block sum of k_kpp_dist (one per thread); the tiled kernel uses 128
@@ -341,6 +344,215 @@ static void launch_kpp_dist_tile(const float *X, int64_t n, int d, int n_cand, c
                        nblk, w.stride, batch);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same distances on the fp64 matrix pipe.  v_mfma_f64_16x16x4_f64 takes ONE double per lane and
+// operand for 2048 flop, where the register-tiled kernel above reads (8 + CQ) doubles from LDS per
+// 8*CQ multiply-adds.  (Measured with tools/mfma_f64_rate on MI355X: the instruction sustains
+// 47.8 TFLOP/s, plain v_fma_f64 69.5 TFLOP/s; this kernel reaches ~38 TFLOP/s, the tiled
+// multiply-add kernel 24.)  A = candidates (16 rows = the 8-candidate tiles of two
+// restarts), B = points (16 columns), k = features in ascending groups of four; the accumulator
+// of (candidate, point) sees the same products in the same order as the fma chain (checked
+// bit for bit against k_kpp_dist_tile by tests/test_gpu_batched.py).
+//   workgroup: 128 points x NC candidates, 4 waves as WP (points) x WC (candidates);
+//   wave: PB 16-point blocks x QB 16-candidate blocks, 4 doubles of accumulator per block and lane:
+//         lane (g = lane / 16, j = lane % 16), register r  <->  candidate 4 r + g, point j.
+// LDS chunks of 8 features, double buffered, rows padded so that the four k rows one operand read
+// touches fall into different 128-byte bank groups.
+// ------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+static constexpr int KPP_MK = 8;   // features per LDS chunk of the MFMA kernel
+
+template <int WP, int QB, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__restrict__ X, int64_t n, int d, int n_cand,
+                                                          const double *__restrict__ cand_x0,
+                                                          const double *__restrict__ cand_xx0,
+                                                          const double *__restrict__ yy, const float *rows_prev0,
+                                                          const int32_t *sel_prev0, int has_prev, float *rows_out0,
+                                                          double *bsum_out0, int64_t nblk, size_t bstride,
+                                                          int batch) {
+    constexpr int WC = 4 / WP;            // waves along the candidate axis
+    constexpr int PB = 8 / WP;            // 16-point blocks per wave
+    constexpr int NC = WC * QB * 16;      // candidate columns per workgroup
+    constexpr int RB = NC / 8;            // restarts per workgroup
+    constexpr int YS = KPP_TP + 16;
+    constexpr int CS = NC + 16 + ((NC % 32) ? 16 : 0);
+    __shared__ __attribute__((aligned(16))) double ys_[2][KPP_MK][YS];
+    __shared__ __attribute__((aligned(16))) double cs_[2][KPP_MK][CS];
+    __shared__ double part[WP][NC];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: restart indices / pointers stay scalar
+    const int j = lane & 15, g = lane >> 4;
+    const int wp = wave % WP, wc = wave / WP;
+    const int64_t row0 = (int64_t)blockIdx.x * KPP_TP;
+    const int b0 = blockIdx.y * RB;
+
+    f64x4 acc[PB][QB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc[p][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+    constexpr int XPIECES = KPP_TP * (KPP_MK / 4);               // float4 pieces of X per chunk (256)
+    static_assert(XPIECES == 256, "one float4 of X per thread and chunk");
+    constexpr int CPIECES = RB * KPP_MK * 4;                     // double2 pieces of the candidate tiles
+    constexpr int CV = (CPIECES + 255) / 256;
+    // The first hop of the epilogue's dependent loads (which of the previous rows is the closest-so-far
+    // one: wave-uniform) and |y|^2 are requested now, behind the MFMA loop.
+    double yyv[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int64_t i = row0 + (wp * PB + p) * 16 + j;
+        yyv[p] = yy[i < n ? i : n - 1];
+    }
+    int selv[QB][2];
+#pragma unroll
+    for (int q = 0; q < QB; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = b0 + (wc * QB + q) * 2 + h;
+            selv[q][h] = (b < batch && has_prev) ? *kpp_at(sel_prev0, bstride, b) : 0;
+        }
+
+    // Global loads run TWO chunks ahead of the MFMAs (two register sets, loop unrolled by two): one
+    // chunk's MFMAs are shorter than a trip to L2 / HBM.
+    struct Regs {
+        float4 x;
+        double2 c[CV];
+    };
+    Regs ra, rb;
+    auto fetch = [&](int kc, Regs &rg) {
+        {
+            const int r = tid / (KPP_MK / 4), q4 = tid % (KPP_MK / 4);
+            int64_t row = row0 + r;
+            if (row >= n) row = n - 1;
+            rg.x = *reinterpret_cast<const float4 *>(X + row * d + kc + 4 * q4);
+        }
+#pragma unroll
+        for (int i = 0; i < CV; ++i) {
+            const int e = tid + 256 * i;  // double2 index: restart rb, pair w2 of its KPP_MK x 8 chunk
+            const int rbi = e / (KPP_MK * 4), w2 = e % (KPP_MK * 4);
+            const int b = b0 + rbi;
+            rg.c[i] = make_double2(0.0, 0.0);
+            if (e < CPIECES && b < batch)
+                rg.c[i] = *reinterpret_cast<const double2 *>(kpp_at(cand_x0, bstride, b) + (size_t)kc * 8 + 2 * w2);
+        }
+    };
+    auto deposit = [&](int buf, const Regs &rg) {
+        {
+            const int r = tid / (KPP_MK / 4), q4 = tid % (KPP_MK / 4);
+            ys_[buf][4 * q4 + 0][r] = (double)rg.x.x;
+            ys_[buf][4 * q4 + 1][r] = (double)rg.x.y;
+            ys_[buf][4 * q4 + 2][r] = (double)rg.x.z;
+            ys_[buf][4 * q4 + 3][r] = (double)rg.x.w;
+        }
+#pragma unroll
+        for (int i = 0; i < CV; ++i) {
+            const int e = tid + 256 * i;
+            const int rbi = e / (KPP_MK * 4), w2 = e % (KPP_MK * 4);
+            if (e < CPIECES) *reinterpret_cast<double2 *>(&cs_[buf][w2 >> 2][rbi * 8 + 2 * (w2 & 3)]) = rg.c[i];
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int s4 = 0; s4 < KPP_MK / 4; ++s4) {
+            double bv[PB], av[QB];
+#pragma unroll
+            for (int p = 0; p < PB; ++p) bv[p] = ys_[buf][4 * s4 + g][(wp * PB + p) * 16 + j];
+#pragma unroll
+            for (int q = 0; q < QB; ++q) av[q] = cs_[buf][4 * s4 + g][(wc * QB + q) * 16 + j];
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+#pragma unroll
+                for (int p = 0; p < PB; ++p)
+                    acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[p], acc[p][q], 0, 0, 0);
+        }
+    };
+
+    // d is a multiple of 16 (kpp_tile_path): an even number of chunks
+    fetch(0, ra);
+    fetch(KPP_MK, rb);
+    for (int kc = 0; kc < d; kc += 2 * KPP_MK) {
+        deposit(0, ra);
+        __syncthreads();  // chunk visible; every wave is past the MFMAs that read this buffer two chunks ago
+        if (kc + 2 * KPP_MK < d) fetch(kc + 2 * KPP_MK, ra);
+        compute(0);
+        deposit(1, rb);
+        __syncthreads();
+        if (kc + 3 * KPP_MK < d) fetch(kc + 3 * KPP_MK, rb);
+        compute(1);
+    }
+
+    // epilogue: distance, clamp, min with the closest-so-far row, store, block sums
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        // accumulator register r of lane group g is candidate row 4 r + g of the block: registers 0, 1
+        // belong to the block's first restart (candidates g, 4 + g), registers 2, 3 to its second
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = b0 + (wc * QB + q) * 2 + h;
+            const bool live = b < batch;
+            const float *prev = (live && has_prev) ? kpp_at(rows_prev0, bstride, b) + (size_t)selv[q][h] * n : nullptr;
+            float oldv[PB];
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const int64_t i = row0 + (wp * PB + p) * 16 + j;
+                oldv[p] = (prev != nullptr && i < n) ? prev[i] : __builtin_inff();
+            }
+            double cxx[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) cxx[e] = (live && 4 * e + g < n_cand) ? kpp_at(cand_xx0, bstride, b)[4 * e + g] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * h + e, l = 4 * e + g;
+                const bool use = live && l < n_cand;  // uniform per 16-lane group
+                double sum = 0.0;
+                if (use) {
+                    float *rows_out = kpp_at(rows_out0, bstride, b) + (size_t)l * n;
+#pragma unroll
+                    for (int p = 0; p < PB; ++p) {
+                        const int64_t i = row0 + (wp * PB + p) * 16 + j;
+                        if (i < n) {
+                            double dd = -2.0 * acc[p][q][r];
+                            dd += cxx[e];
+                            dd += yyv[p];
+                            float f = (float)dd;
+                            f = f > 0.f ? f : 0.f;                    // np.maximum(d, 0)
+                            f = f < oldv[p] ? f : oldv[p];      // np.minimum(closest_dist_sq, distance_to_candidates)
+                            rows_out[i] = f;
+                            sum += (double)f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+                if (j == 0) part[wp][(wc * QB + q) * 16 + 8 * h + l] = sum;
+            }
+        }
+    }
+    __syncthreads();
+    // block sums: the WP point slices of the workgroup in ascending order
+    for (int col = tid; col < NC; col += 256) {
+        const int b = b0 + (col >> 3), l = col & 7;
+        if (b < batch && l < n_cand) {
+            double t = part[0][col];
+#pragma unroll
+            for (int w = 1; w < WP; ++w) t += part[w][col];
+            kpp_at(bsum_out0, bstride, b)[(size_t)l * nblk + blockIdx.x] = t;
+        }
+    }
+}
+
+template <int WP, int QB, int MINB = 2>
+static void launch_kpp_dist_mfma(const float *X, int64_t n, int d, int n_cand, const KppWs &w, const float *rows_prev,
+                                 int has_prev, float *rows_out, double *bsum_out, int64_t nblk, int batch,
+                                 hipStream_t s) {
+    constexpr int RB = (4 / WP) * QB * 2;
+    hipLaunchKernelGGL((k_kpp_dist_mfma<WP, QB, MINB>), dim3((unsigned)nblk, (unsigned)((batch + RB - 1) / RB)), dim3(256), 0, s,
+                       X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out, nblk,
+                       w.stride, batch);
+}
+
 __host__ inline bool kpp_tile_path(int d, int l) { return d % KPP_KC == 0 && l <= 8; }
 
 static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const KppWs &w, const float *rows_prev,
@@ -348,6 +560,19 @@ static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const K
                            hipStream_t s) {
     const dim3 grid((unsigned)nblk, (unsigned)batch), block(256);
     if (kpp_tile_path(d, ltile == 8 ? 8 : 16)) {
+        // MTP_KPP_KERNEL=fma selects the multiply-add chain kernel the MFMA kernel is verified against
+        const char *sel = getenv("MTP_KPP_KERNEL");
+        if (sel == nullptr || strcmp(sel, "fma") != 0) {
+            // 4 restarts (32 candidate rows) per workgroup column: 80 VGPRs, 6 workgroups per CU, so the grid
+            // quantises finely (eth: 2875 workgroups on 1536 slots) and every SIMD holds waves of 6 different
+            // workgroups; wider columns (8, 10, 20 restarts) measured 71-86 us against 63 us per step
+            if (batch > 2)
+                launch_kpp_dist_mfma<4, 2, 6>(X, n, d, n_cand, w, rows_prev, has_prev, rows_out, bsum_out, nblk, batch, s);
+            else
+                launch_kpp_dist_mfma<4, 1, 6>(X, n, d, n_cand, w, rows_prev, has_prev, rows_out, bsum_out, nblk, batch, s);
+            MTP_LAUNCH_CHECK();
+            return MTP_OK;
+        }
         // candidates per thread: 10 covers the reference's 20 restarts in one workgroup column
         if (batch > 8)
             launch_kpp_dist_tile<5>(X, n, d, n_cand, w, rows_prev, has_prev, rows_out, bsum_out, nblk, batch, s);

@@ -31,6 +31,28 @@ def test_batched_seeding_equals_single(n, d, k, b, gpu_device):
         assert torch.equal(ib[r], i1) and torch.equal(cb[r], c1)
 
 
+@pytest.mark.parametrize("n,d,k,b", [(3001, 96, 40, 1), (2500, 128, 25, 3), (4099, 64, 30, 6), (3333, 96, 64, 20),
+                                     (1500, 96, 16, 23)])
+def test_seeding_mfma_kernel_equals_fma_chain_kernel(n, d, k, b, gpu_device, monkeypatch):
+    """The fp64-MFMA distance kernel (every instantiation: 1-2, 3-4, 5-8, 9+ restarts per workgroup column,
+    and more restarts than one column holds) against the multiply-add chain kernel it replaces: same
+    seeds, same centres.  (tools/mfma_f64_order checks the instruction's accumulation order itself.)"""
+    from pccs_accel import seeding
+    X = datagen.make_encodings(300 + n, n, d, 9)
+    Xc = dev(X - X.mean(axis=0), gpu_device)
+    rs = np.random.RandomState(4)
+    draws = [seeding.draw(rs, n, k) for _ in range(b)]
+    monkeypatch.setenv("MTP_KPP_KERNEL", "fma")
+    c_fma, i_fma = seeding.kmeans_plusplus_batched(Xc, k, draws)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("MTP_KPP_KERNEL")
+    c_mfma, i_mfma = seeding.kmeans_plusplus_batched(Xc, k, draws)
+    assert torch.equal(i_fma, i_mfma) and torch.equal(c_fma, c_mfma)
+    # and against the CPU oracle's replay of sklearn, restart 0
+    oc, oi = O.kmeans_plusplus(np.ascontiguousarray(Xc.cpu().numpy()), k, np.random.RandomState(4))
+    assert np.array_equal(i_mfma[0].cpu().numpy(), oi)
+
+
 @pytest.mark.parametrize("check_every", [1, 4])
 def test_batched_lloyd_equals_single_with_relocation(check_every, gpu_device):
     from pccs_accel import kernels as K
