@@ -133,24 +133,41 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
             for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[pt][r] = 0.f;
-            // A operands one u-step ahead of the MFMAs that use them; the compiler fence keeps it
-            // from hoisting all D/8 ds_read_b128 to the top (64 VGPRs) and spilling.
+            // A operands one u-step ahead of the MFMAs that use them (written as `an = next; mfma(a); a = an`
+            // the two sets were merged into one register quad and every read was waited for at once).
             float4 a = arow[0];
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+            {
+                static_assert((D / 8) % 2 == 0, "u-steps are taken two at a time");
+                // two explicit operand sets, alternating: the ds_read of step u+1 is issued BEFORE the four
+                // MFMAs of step u (scheduling barriers pin the order; the register allocator cannot merge
+                // the sets because both are live across the MFMAs), so its latency passes behind them
+                float4 b = a;
 #pragma unroll
-            for (int u = 0; u < D / 8; ++u) {
-                float4 an = a;
-                if (u + 1 < D / 8) an = arow[2 * (u + 1)];
+                for (int u = 0; u < D / 8; u += 2) {
+                    b = arow[2 * (u + 1)];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xr[pt][4 * u + 0], acc[pt], 0, 0, 0);
+                    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xr[pt][4 * u + 0], acc[pt], 0, 0, 0);
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xr[pt][4 * u + 1], acc[pt], 0, 0, 0);
+                    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xr[pt][4 * u + 1], acc[pt], 0, 0, 0);
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xr[pt][4 * u + 2], acc[pt], 0, 0, 0);
+                    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xr[pt][4 * u + 2], acc[pt], 0, 0, 0);
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xr[pt][4 * u + 3], acc[pt], 0, 0, 0);
-                asm volatile("" ::: "memory");
-                a = an;
+                    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xr[pt][4 * u + 3], acc[pt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u + 2 < D / 8) a = arow[2 * (u + 2)];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, xr[pt][4 * u + 4], acc[pt], 0, 0, 0);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, xr[pt][4 * u + 5], acc[pt], 0, 0, 0);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, xr[pt][4 * u + 6], acc[pt], 0, 0, 0);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, xr[pt][4 * u + 7], acc[pt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
             if constexpr (!EPI) {  // ablation: keep the accumulators alive, skip the epilogue
