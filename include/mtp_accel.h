@@ -184,6 +184,22 @@ int mtp_kmeans_plusplus_batched_f32(const float *X, int64_t n, int d, int k, int
                                     const double *u, int64_t *indices_out, float *centers_out, void *ws,
                                     size_t ws_bytes, void *stream);
 
+/* Step-level pieces of the same seeding for ROW-SHARDED points (one process per GPU; the host side
+ * -- pccs_accel.seeding.kmeans_plusplus_sharded -- locates the draws through an exchange of the ranks'
+ * cumulative sums and passes every rank the same candidate rows).  sklearn cluster/_kmeans.py:222-262.
+ *   mtp_kpp_row_sqnorm_f64: yy[i] = |x_i|^2 in double (the YY term of sklearn's upcast
+ *     _euclidean_distances, metrics/pairwise.py:391-442), computed once per fit.
+ *   mtp_kpp_candidate_dists_f32: rows_out[b, l, i] = min(closest[b, i], fp32(max(0, |c_bl|^2 - 2 c_bl.x_i + |x_i|^2)))
+ *     for the n_cand (<= 8) candidate rows cand[b, l, :] of each of `batch` restarts and this rank's n
+ *     points (closest == NULL: no minimum, the first centre), and pot_out[b, l] = sum_i rows_out[b, l, i]
+ *     (double; the rank-local part of sklearn's candidates_pot).  d must be a multiple of 16.
+ *     ws: mtp_kpp_candidate_dists_workspace_bytes(n, d, batch) bytes. */
+int64_t mtp_kpp_candidate_dists_workspace_bytes(int64_t n, int d, int batch);
+int mtp_kpp_row_sqnorm_f64(const float *X, int64_t n, int d, double *yy, void *stream);
+int mtp_kpp_candidate_dists_f32(const float *X, int64_t n, int d, const double *yy, const float *cand, int batch,
+                                int n_cand, const float *closest, float *rows_out, double *pot_out, void *ws,
+                                size_t ws_bytes, void *stream);
+
 /* Best-of-K ADE/FDE.  pred [n, kstride, t, 2], gt [n, t, 2]; the first k (<= kstride)
  * candidates of every agent are scored:
  *   ADE_c = (sum_t ||gt_t - pred_c,t||) / ade_div,  FDE_c = ||gt_T - pred_c,T||

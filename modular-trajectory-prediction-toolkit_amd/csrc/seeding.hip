@@ -363,13 +363,21 @@ static void launch_kpp_dist_tile(const float *X, int64_t n, int d, int n_cand, c
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 static constexpr int KPP_MK = 8;   // features per LDS chunk of the MFMA kernel
 
+// Byte strides from one restart's array to the next.  The fused seeding keeps everything in one
+// workspace block per restart (all strides equal); mtp_kpp_candidate_dists_f32 runs the kernel on
+// caller-owned arrays with their own pitches.
+struct KppStrides {
+    size_t cand_x, cand_xx, rows_prev, sel, rows_out, bsum;
+};
+__host__ inline KppStrides kpp_uniform_strides(size_t s) { return KppStrides{s, s, s, s, s, s}; }
+
 template <int WP, int QB, int MINB = 2>
 __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__restrict__ X, int64_t n, int d, int n_cand,
                                                           const double *__restrict__ cand_x0,
                                                           const double *__restrict__ cand_xx0,
                                                           const double *__restrict__ yy, const float *rows_prev0,
                                                           const int32_t *sel_prev0, int has_prev, float *rows_out0,
-                                                          double *bsum_out0, int64_t nblk, size_t bstride,
+                                                          double *bsum_out0, int64_t nblk, KppStrides st,
                                                           int batch) {
     constexpr int WC = 4 / WP;            // waves along the candidate axis
     constexpr int PB = 8 / WP;            // 16-point blocks per wave
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int b = b0 + (wc * QB + q) * 2 + h;
-            selv[q][h] = (b < batch && has_prev) ? *kpp_at(sel_prev0, bstride, b) : 0;
+            selv[q][h] = (b < batch && has_prev) ? *kpp_at(sel_prev0, st.sel, b) : 0;
         }
 
     // Global loads run TWO chunks ahead of the MFMAs (two register sets, loop unrolled by two): one
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
             const int b = b0 + rbi;
             rg.c[i] = make_double2(0.0, 0.0);
             if (e < CPIECES && b < batch)
-                rg.c[i] = *reinterpret_cast<const double2 *>(kpp_at(cand_x0, bstride, b) + (size_t)kc * 8 + 2 * w2);
+                rg.c[i] = *reinterpret_cast<const double2 *>(kpp_at(cand_x0, st.cand_x, b) + (size_t)kc * 8 + 2 * w2);
         }
     };
     auto deposit = [&](int buf, const Regs &rg) {
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
         for (int h = 0; h < 2; ++h) {
             const int b = b0 + (wc * QB + q) * 2 + h;
             const bool live = b < batch;
-            const float *prev = (live && has_prev) ? kpp_at(rows_prev0, bstride, b) + (size_t)selv[q][h] * n : nullptr;
+            const float *prev = (live && has_prev) ? kpp_at(rows_prev0, st.rows_prev, b) + (size_t)selv[q][h] * n : nullptr;
             float oldv[PB];
 #pragma unroll
             for (int p = 0; p < PB; ++p) {
@@ -501,14 +509,14 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
             }
             double cxx[2];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) cxx[e] = (live && 4 * e + g < n_cand) ? kpp_at(cand_xx0, bstride, b)[4 * e + g] : 0.0;
+            for (int e = 0; e < 2; ++e) cxx[e] = (live && 4 * e + g < n_cand) ? kpp_at(cand_xx0, st.cand_xx, b)[4 * e + g] : 0.0;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int r = 2 * h + e, l = 4 * e + g;
                 const bool use = live && l < n_cand;  // uniform per 16-lane group
                 double sum = 0.0;
                 if (use) {
-                    float *rows_out = kpp_at(rows_out0, bstride, b) + (size_t)l * n;
+                    float *rows_out = kpp_at(rows_out0, st.rows_out, b) + (size_t)l * n;
 #pragma unroll
                     for (int p = 0; p < PB; ++p) {
                         const int64_t i = row0 + (wp * PB + p) * 16 + j;
@@ -538,19 +546,35 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
             double t = part[0][col];
 #pragma unroll
             for (int w = 1; w < WP; ++w) t += part[w][col];
-            kpp_at(bsum_out0, bstride, b)[(size_t)l * nblk + blockIdx.x] = t;
+            kpp_at(bsum_out0, st.bsum, b)[(size_t)l * nblk + blockIdx.x] = t;
         }
     }
 }
 
 template <int WP, int QB, int MINB = 2>
-static void launch_kpp_dist_mfma(const float *X, int64_t n, int d, int n_cand, const KppWs &w, const float *rows_prev,
-                                 int has_prev, float *rows_out, double *bsum_out, int64_t nblk, int batch,
+static void launch_kpp_dist_mfma(const float *X, int64_t n, int d, int n_cand, const double *cand_x, const double *cand_xx,
+                                 const double *yy, const float *rows_prev, const int32_t *sel_prev, int has_prev,
+                                 float *rows_out, double *bsum_out, int64_t nblk, KppStrides st, int batch,
                                  hipStream_t s) {
     constexpr int RB = (4 / WP) * QB * 2;
     hipLaunchKernelGGL((k_kpp_dist_mfma<WP, QB, MINB>), dim3((unsigned)nblk, (unsigned)((batch + RB - 1) / RB)), dim3(256), 0, s,
-                       X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out, nblk,
-                       w.stride, batch);
+                       X, n, d, n_cand, cand_x, cand_xx, yy, rows_prev, sel_prev, has_prev, rows_out, bsum_out, nblk, st,
+                       batch);
+}
+
+// 4 restarts (32 candidate rows) per workgroup column: 80 VGPRs, 6 workgroups per CU, so the grid
+// quantises finely (eth: 2875 workgroups on 1536 slots) and every SIMD holds waves of 6 different
+// workgroups; wider columns (8, 10, 20 restarts) measured 71-86 us against 63 us per step
+static void launch_kpp_dist_mfma_any(const float *X, int64_t n, int d, int n_cand, const double *cand_x,
+                                     const double *cand_xx, const double *yy, const float *rows_prev,
+                                     const int32_t *sel_prev, int has_prev, float *rows_out, double *bsum_out,
+                                     int64_t nblk, KppStrides st, int batch, hipStream_t s) {
+    if (batch > 2)
+        launch_kpp_dist_mfma<4, 2, 6>(X, n, d, n_cand, cand_x, cand_xx, yy, rows_prev, sel_prev, has_prev, rows_out, bsum_out,
+                                      nblk, st, batch, s);
+    else
+        launch_kpp_dist_mfma<4, 1, 6>(X, n, d, n_cand, cand_x, cand_xx, yy, rows_prev, sel_prev, has_prev, rows_out, bsum_out,
+                                      nblk, st, batch, s);
 }
 
 __host__ inline bool kpp_tile_path(int d, int l) { return d % KPP_KC == 0 && l <= 8; }
@@ -563,13 +587,8 @@ static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const K
         // MTP_KPP_KERNEL=fma selects the multiply-add chain kernel the MFMA kernel is verified against
         const char *sel = getenv("MTP_KPP_KERNEL");
         if (sel == nullptr || strcmp(sel, "fma") != 0) {
-            // 4 restarts (32 candidate rows) per workgroup column: 80 VGPRs, 6 workgroups per CU, so the grid
-            // quantises finely (eth: 2875 workgroups on 1536 slots) and every SIMD holds waves of 6 different
-            // workgroups; wider columns (8, 10, 20 restarts) measured 71-86 us against 63 us per step
-            if (batch > 2)
-                launch_kpp_dist_mfma<4, 2, 6>(X, n, d, n_cand, w, rows_prev, has_prev, rows_out, bsum_out, nblk, batch, s);
-            else
-                launch_kpp_dist_mfma<4, 1, 6>(X, n, d, n_cand, w, rows_prev, has_prev, rows_out, bsum_out, nblk, batch, s);
+            launch_kpp_dist_mfma_any(X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy, rows_prev, w.state, has_prev, rows_out,
+                                     bsum_out, nblk, kpp_uniform_strides(w.stride), batch, s);
             MTP_LAUNCH_CHECK();
             return MTP_OK;
         }
@@ -843,4 +862,129 @@ extern "C" int mtp_kmeans_plusplus_batched_f32(const float *X, int64_t n, int d,
                                                float *centers_out, void *ws, size_t ws_bytes, void *stream) {
     MTP_REQUIRE(center_ids != nullptr, "mtp_kmeans_plusplus_batched: center_ids is NULL");
     return kpp_run(X, n, d, k, l, batch, 0, center_ids, u, indices_out, centers_out, ws, ws_bytes, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Step-level pieces for seeding over row-sharded points (pccs_accel.seeding.kmeans_plusplus_sharded):
+// every rank holds a block of rows; the candidate rows of a step are exchanged by the host side
+// (they are L rows per restart), and each rank computes their distances to ITS points here.
+// ------------------------------------------------------------------------------------------
+
+// candidate rows (float, [batch][n_cand][d]) -> the kernels' operand form: double, feature-major
+// [d][8] per restart, and |x|^2 summed exactly as k_kpp_select / k_kpp_first do (lane-strided
+// partial sums, xor tree), so a one-rank run carries the fused path's bits.
+__global__ __launch_bounds__(64) void k_kpp_stage_cands(const float *__restrict__ cand, int d, int n_cand,
+                                                        double *cand_x, double *cand_xx) {
+    const int b = blockIdx.y, l = blockIdx.x, lane = threadIdx.x;
+    const float *x = cand + ((size_t)b * n_cand + l) * d;
+    double *cx = cand_x + (size_t)b * d * 8;
+    double xx = 0.0;
+    for (int k = lane; k < d; k += 64) {
+        const double v = (double)x[k];
+        cx[(size_t)k * 8 + l] = v;
+        xx += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
+    if (lane == 0) cand_xx[(size_t)b * 8 + l] = xx;
+}
+
+// potentials of the candidate rows = sums of their block sums, in k_kpp_select's order
+__global__ __launch_bounds__(1024) void k_kpp_potentials(const double *__restrict__ bsum, int64_t nblk, int n_cand,
+                                                         double *pot) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *bs = bsum + (size_t)blockIdx.x * 8 * nblk;
+    for (int l = 0; l < n_cand; ++l) {
+        double v = 0.0;
+        for (int64_t b = tid; b < nblk; b += 1024) v += bs[(size_t)l * nblk + b];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 16; ++w) t += red[w];
+            pot[(size_t)blockIdx.x * n_cand + l] = t;
+        }
+        __syncthreads();
+    }
+}
+
+struct KppCandWs {
+    double *cand_x;   // [batch][d][8]
+    double *cand_xx;  // [batch][8]
+    double *bsum;     // [batch][8][nblk]
+    int32_t *zero;    // one int = 0: "the closest-so-far row is row 0 of its array"
+    size_t bytes;
+};
+
+static KppCandWs kpp_cand_carve(void *ws, int64_t n, int d, int batch) {
+    KppCandWs w;
+    const int64_t nblk = (n + KPP_TP - 1) / KPP_TP;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *p = ws ? static_cast<char *>(ws) + off : nullptr;
+        off += kpp_align(bytes);
+        return p;
+    };
+    w.cand_x = static_cast<double *>(take((size_t)batch * d * 8 * 8));
+    w.cand_xx = static_cast<double *>(take((size_t)batch * 8 * 8));
+    w.bsum = static_cast<double *>(take((size_t)batch * 8 * nblk * 8));
+    w.zero = static_cast<int32_t *>(take(64));
+    w.bytes = off;
+    return w;
+}
+
+extern "C" int64_t mtp_kpp_candidate_dists_workspace_bytes(int64_t n, int d, int batch) {
+    if (n <= 0 || d <= 0 || batch <= 0) return 0;
+    return (int64_t)kpp_cand_carve(nullptr, n, d, batch).bytes;
+}
+
+extern "C" int mtp_kpp_row_sqnorm_f64(const float *X, int64_t n, int d, double *yy, void *stream) {
+    MTP_REQUIRE(n >= 0 && d >= 1, "mtp_kpp_row_sqnorm_f64: bad shape");
+    if (n == 0) return MTP_OK;
+    MTP_REQUIRE(X && yy, "mtp_kpp_row_sqnorm_f64: null pointer");
+    hipLaunchKernelGGL(k_kpp_rownorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mtp_stream(stream), X, n, d, yy);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+extern "C" int mtp_kpp_candidate_dists_f32(const float *X, int64_t n, int d, const double *yy, const float *cand,
+                                           int batch, int n_cand, const float *closest, float *rows_out,
+                                           double *pot_out, void *ws, size_t ws_bytes, void *stream) {
+    MTP_REQUIRE(n >= 0 && d >= 1 && batch >= 1 && batch <= 65535, "mtp_kpp_candidate_dists: bad shape n=%lld d=%d batch=%d",
+                (long long)n, d, batch);
+    MTP_REQUIRE(n_cand >= 1 && n_cand <= 8, "mtp_kpp_candidate_dists: 1..8 candidates per restart (got %d)", n_cand);
+    MTP_REQUIRE(d % 16 == 0, "mtp_kpp_candidate_dists: d must be a multiple of 16 (got %d)", d);
+    MTP_REQUIRE(cand && pot_out && ws, "mtp_kpp_candidate_dists: null pointer");
+    hipStream_t s = mtp_stream(stream);
+    if (n == 0) {  // a rank without rows: zero potentials
+        MTP_HIP(hipMemsetAsync(pot_out, 0, (size_t)batch * n_cand * sizeof(double), s));
+        return MTP_OK;
+    }
+    MTP_REQUIRE(X && yy && rows_out, "mtp_kpp_candidate_dists: null pointer");
+    KppCandWs w = kpp_cand_carve(ws, n, d, batch);
+    if (ws_bytes < w.bytes) {
+        mtp_set_error("mtp_kpp_candidate_dists: workspace of %zu bytes, need %zu", ws_bytes, w.bytes);
+        return MTP_E_WORKSPACE;
+    }
+    const int64_t nblk = (n + KPP_TP - 1) / KPP_TP;
+    MTP_REQUIRE(nblk <= 0x7fffffff, "mtp_kpp_candidate_dists: n too large");
+    MTP_HIP(hipMemsetAsync(w.zero, 0, 64, s));
+    // candidates beyond n_cand keep whatever the tile holds: their products are never read
+    hipLaunchKernelGGL(k_kpp_stage_cands, dim3(n_cand, batch), dim3(64), 0, s, cand, d, n_cand, w.cand_x, w.cand_xx);
+    MTP_LAUNCH_CHECK();
+    KppStrides st;
+    st.cand_x = (size_t)d * 8 * sizeof(double);
+    st.cand_xx = 8 * sizeof(double);
+    st.rows_prev = (size_t)n * sizeof(float);
+    st.sel = 0;
+    st.rows_out = (size_t)n_cand * n * sizeof(float);
+    st.bsum = (size_t)8 * nblk * sizeof(double);
+    launch_kpp_dist_mfma_any(X, n, d, n_cand, w.cand_x, w.cand_xx, yy, closest, w.zero, closest != nullptr ? 1 : 0, rows_out,
+                             w.bsum, nblk, st, batch, s);
+    MTP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_kpp_potentials, dim3(batch), dim3(1024), 0, s, w.bsum, nblk, n_cand, pot_out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
 }

@@ -332,31 +332,97 @@ class ShardedLloyd:
         return self.labels, float(inertia.item()), centers, n_iter
 
 
-def kmeans_fit_sharded(X_local, n_total, C0, row_offset, tol=1e-4, max_iter=300, check_every=1, group=None,
-                       force_collectives=False, lagged_steps=0):
-    """KMeans(init=C0, n_init=1).fit over row-sharded, un-centred points: global mean / tolerance
-    by all-reduce of column sums, then ShardedLloyd.  C0 (un-centred) identical on every rank."""
-    from . import kernels as K
+def is_same_clustering_sharded(l1, l2, k, collective, group=None):
+    """sklearn cluster/_k_means_common.pyx:314-328 over sharded labels: l1 -> l2 is a function iff, for every
+    label of l1, the smallest and the largest l2 seen with it -- over all ranks -- coincide."""
+    dev = l1.device
+    mn = torch.full((k,), k, dtype=torch.int64, device=dev)
+    mx = torch.full((k,), -1, dtype=torch.int64, device=dev)
+    if l1.numel():
+        a, b = l1.to(torch.int64), l2.to(torch.int64)
+        mn.scatter_reduce_(0, a, b, reduce="amin", include_self=True)
+        mx.scatter_reduce_(0, a, b, reduce="amax", include_self=True)
+    if collective:
+        for t, op in ((mn, dist.ReduceOp.MIN), (mx, dist.ReduceOp.MAX)):
+            if t.is_cuda and _host_staged(group):
+                h = t.cpu()
+                dist.all_reduce(h, op=op, group=group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=op, group=group)
+    seen = mx >= 0
+    return bool((mn[seen] == mx[seen]).all())
+
+
+def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_iter=300, check_every=1, group=None,
+                       force_collectives=False, lagged_steps=0, n_clusters=None, n_init=20, random_state=None,
+                       lloyd_ops=None, seed_ops=None, stats=None):
+    """sklearn ``KMeans.fit`` over row-sharded, un-centred points (one process per GPU): global mean /
+    tolerance by all-reduce of column sums, then
+
+      * ``C0`` given (un-centred [K, D], identical on every rank): ``KMeans(init=C0, n_init=1)``;
+      * ``C0`` None: ``KMeans(n_clusters, n_init=n_init)`` with k-means++ seeding -- all restarts are seeded in
+        lock step (``seeding.kmeans_plusplus_sharded``), each runs ``ShardedLloyd``, and the best is kept by
+        sklearn's rule (cluster/_kmeans.py:1525-1532).  ``random_state`` must denote the SAME stream on every
+        rank: an int, or None with ``np.random.seed(s)`` called identically in every process.
+
+    Returns dict(labels (local), centers, inertia, n_iter, tol_abs).  ``lloyd_ops`` / ``seed_ops`` / ``stats``
+    (precomputed (col_sum, col_sqdev) functions) are test hooks standing in for the HIP kernels."""
+    from . import seeding
     rank, ws = world()
     collective = ws > 1 or (force_collectives and dist.is_initialized())
-    col_sum = K.col_sums(X_local)
+    if stats is None:
+        from . import kernels as K
+        col_sums, col_sqdev, sub_rowvec_ = K.col_sums, K.col_sqdev, K.sub_rowvec_
+    else:
+        col_sums, col_sqdev, sub_rowvec_ = stats
+    col_sum = col_sums(X_local)
     if collective:
         all_reduce_sum(col_sum, group)
     mean64 = col_sum / n_total
-    sqdev = K.col_sqdev(X_local, mean64)
+    sqdev = col_sqdev(X_local, mean64)
     if collective:
         all_reduce_sum(sqdev, group)
     tol_abs = float((sqdev / n_total).mean().item()) * tol if tol != 0 else 0.0
     mean32 = mean64.to(torch.float32)
     Xc = X_local.clone()
-    K.sub_rowvec_(Xc, mean32)
-    C0c = C0.clone().contiguous()
-    K.sub_rowvec_(C0c, mean32)
-    sl = ShardedLloyd(Xc, C0c, row_offset=row_offset, group=group, force_collectives=force_collectives)
-    if lagged_steps:  # the first iterations with the flags read one step late (ShardedLloyd.run_fixed)
-        sl.run_fixed(min(lagged_steps, max_iter), tol_abs, max_iter)
-    labels, inertia, centers, n_iter = sl.run(max_iter=max_iter, tol_abs=tol_abs, check_every=check_every)
-    return dict(labels=labels, centers=centers + mean32, inertia=inertia, n_iter=n_iter, tol_abs=tol_abs)
+    sub_rowvec_(Xc, mean32)
+
+    def lloyd(c0c):
+        sl = ShardedLloyd(Xc, c0c, row_offset=row_offset, group=group, force_collectives=force_collectives, ops=lloyd_ops)
+        if lagged_steps:  # the first iterations with the flags read one step late (ShardedLloyd.run_fixed)
+            sl.run_fixed(min(lagged_steps, max_iter), tol_abs, max_iter)
+        return sl.run(max_iter=max_iter, tol_abs=tol_abs, check_every=check_every)
+
+    if C0 is not None:
+        C0c = C0.clone().contiguous()
+        sub_rowvec_(C0c, mean32)
+        labels, inertia, centers, n_iter = lloyd(C0c)
+        return dict(labels=labels, centers=centers + mean32, inertia=inertia, n_iter=n_iter, tol_abs=tol_abs)
+
+    if n_clusters is None:
+        raise ValueError("kmeans_fit_sharded: give initial centres C0 or n_clusters")
+    if n_total < n_clusters:
+        raise ValueError(f"n_samples={n_total} should be >= n_clusters={n_clusters}.")
+    if random_state is None:
+        rs = np.random.mtrand._rand
+    elif isinstance(random_state, (int, np.integer)):
+        rs = np.random.RandomState(random_state)
+    else:
+        rs = random_state
+    # the draws of every restart, in sklearn's order (seeding consumes the stream, Lloyd does not)
+    draws = [seeding.draw(rs, n_total, n_clusters) for _ in range(n_init)]
+    c0s, _ = seeding.kmeans_plusplus_sharded(Xc, row_offset, n_total, n_clusters, draws, group=group, ops=seed_ops,
+                                             force_collectives=force_collectives)
+    best = None
+    for r in range(n_init):
+        labels, inertia, centers, n_iter = lloyd(c0s[r].contiguous())
+        if best is None or (inertia < best["inertia"] and not is_same_clustering_sharded(
+                labels, best["labels"], n_clusters, collective, group)):
+            best = dict(labels=labels.clone(), centers=centers.clone(), inertia=inertia, n_iter=n_iter)
+    best["centers"] = best["centers"] + mean32
+    best["tol_abs"] = tol_abs
+    return best
 
 
 def best_of_k_sharded(pred_local, gt_local, n_total, mode=0, ade_div=None, best_of=None, group=None,

@@ -96,3 +96,109 @@ def kmeans_plusplus_batched(Xc, n_clusters, draws):
                                                     ptr(centers), ptr(ws), ws_bytes, stream_ptr()),
               "mtp_kmeans_plusplus_batched_f32")
     return centers, indices
+
+
+# ------------------------------------------------------------------------------------------
+# Row-sharded points: one process per GPU
+# ------------------------------------------------------------------------------------------
+class DeviceSeedOps:
+    """The HIP kernels behind the sharded seeding (include/mtp_accel.h, step-level seeding entries)."""
+
+    def row_sqnorm(self, X):
+        n, d = X.shape
+        yy = torch.empty(max(n, 1), dtype=torch.float64, device=X.device)
+        with torch.cuda.device(X.device):
+            check(lib().mtp_kpp_row_sqnorm_f64(ptr(X), n, d, ptr(yy), stream_ptr()), "mtp_kpp_row_sqnorm_f64")
+        return yy
+
+    def candidate_dists(self, X, yy, cand, closest):
+        """cand float32 [B, L, D] -> (rows float32 [B, L, n] = min(closest, d(cand, x)), local potentials float64 [B, L])."""
+        n, d = X.shape
+        b, l, _ = cand.shape
+        dev = X.device
+        rows = torch.empty((b, l, n), dtype=torch.float32, device=dev)
+        pot = torch.empty((b, l), dtype=torch.float64, device=dev)
+        ws_bytes = max(int(lib().mtp_kpp_candidate_dists_workspace_bytes(max(n, 1), d, b)), 256)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib().mtp_kpp_candidate_dists_f32(ptr(X), n, d, ptr(yy), ptr(cand), b, l, ptr(closest), ptr(rows), ptr(pot),
+                                                    ptr(ws), ws_bytes, stream_ptr()), "mtp_kpp_candidate_dists_f32")
+        return rows, pot
+
+
+def _first_argmin(v):
+    """np.argmin along dim 1: the FIRST minimum."""
+    l = v.shape[1]
+    m = v.min(dim=1, keepdim=True).values
+    pos = torch.arange(l, device=v.device).expand_as(v)
+    return torch.where(v == m, pos, torch.full_like(pos, l)).min(dim=1).values
+
+
+def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, group=None, ops=None,
+                            force_collectives=False):
+    """k-means++ (sklearn cluster/_kmeans.py:174-272, unit weights) for ``len(draws)`` restarts in lock
+    step over ROW-SHARDED centred points: this rank holds rows [row_offset, row_offset + n_local) of
+    the n_total.  ``draws``: one ``draw()`` result per restart, identical on every rank.
+
+    Per new centre: (1) every rank's cumulative sum of its closest-distance rows; the ranks' totals
+    are all-gathered and give each rank its offset into the global ``stable_cumsum``; (2) the number
+    of cumulative sums below each draw is counted locally (searchsorted) and all-reduced: the sum IS
+    sklearn's ``searchsorted(cumsum, rand)``; (3) the owners contribute the candidate rows to one
+    all-reduce; (4) each rank computes the candidates' distances to its points with the fp64
+    matrix-pipe kernel and its part of the potentials; one all-reduce of [B, L] doubles; (5) every
+    rank picks the same best candidate.  Returns (centres float32 [B, K, D], indices int64 [B, K]),
+    replicated.  Needs D % 16 == 0 and at most 8 local trials (K <= 1096)."""
+    from . import dist as pdist
+    if ops is None:
+        ops = DeviceSeedOps()
+    rank, ws = pdist.world()
+    collective = ws > 1 or (force_collectives and pdist.dist.is_initialized())
+    dev = X_local.device
+    n_local, d = X_local.shape
+    lo, hi = int(row_offset), int(row_offset) + n_local
+    b = len(draws)
+    ids0 = torch.tensor([c for c, _ in draws], dtype=torch.int64, device=dev)
+    if int(ids0.min()) < 0 or int(ids0.max()) >= n_total:
+        raise ValueError("first-centre index out of range")
+    ar = torch.arange(b, device=dev)
+
+    def fetch_rows(idx):
+        """X[idx] for GLOBAL row indices idx [B, m] -> [B, m, D] on every rank (owners contribute, one all-reduce)."""
+        own = (idx >= lo) & (idx < hi)
+        rows = torch.zeros(idx.shape + (d,), dtype=torch.float32, device=dev)
+        if n_local:
+            rows[own] = X_local[(idx[own] - lo)]
+        if collective:
+            pdist.all_reduce_sum(rows, group)
+        return rows
+
+    yy = ops.row_sqnorm(X_local)
+    indices = torch.empty((b, n_clusters), dtype=torch.int64, device=dev)
+    rows, pot = ops.candidate_dists(X_local, yy, fetch_rows(ids0[:, None]), None)
+    if collective:
+        pdist.all_reduce_sum(pot, group)
+    closest = rows[:, 0, :].contiguous()
+    cur_pot = pot[:, 0].to(torch.float32)  # sklearn's potentials are float32
+    indices[:, 0] = ids0
+    if n_clusters > 1:
+        u = torch.from_numpy(np.ascontiguousarray(np.stack([uu for _, uu in draws]))).to(dev)  # [B, K-1, L]
+    for c in range(1, n_clusters):
+        rand = u[:, c - 1, :] * cur_pot.to(torch.float64)[:, None]
+        cs = torch.cumsum(closest.to(torch.float64), dim=1)
+        if collective:
+            tot = cs[:, -1].contiguous() if n_local else torch.zeros(b, dtype=torch.float64, device=dev)
+            every = pdist.all_gather_cat(tot[None], ws, group)  # [W, B]
+            cs = cs + every[:rank].sum(dim=0)[:, None]
+        cnt = torch.searchsorted(cs, rand.contiguous())  # cumulative sums < draw, per (restart, trial)
+        if collective:
+            pdist.all_reduce_sum(cnt, group)
+        idx = cnt.clamp(max=n_total - 1)
+        rows, pot = ops.candidate_dists(X_local, yy, fetch_rows(idx), closest)
+        if collective:
+            pdist.all_reduce_sum(pot, group)
+        pot32 = pot.to(torch.float32)
+        best = _first_argmin(pot32)
+        closest = rows[ar, best].contiguous()
+        cur_pot = pot32[ar, best]
+        indices[:, c] = idx[ar, best]
+    return fetch_rows(indices), indices

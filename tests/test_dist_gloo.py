@@ -257,6 +257,112 @@ def test_best_of_k_sharded_means(world, tmp_path):
         assert np.array_equal(np.concatenate([p[f"idx{mode}"] for p in parts]), o["idx"])
 
 
+class NumpySeedOps:
+    """CPU model of the step-level seeding entry points (oracle arithmetic)."""
+
+    def row_sqnorm(self, X):
+        return torch.zeros(max(X.shape[0], 1), dtype=torch.float64)
+
+    def candidate_dists(self, X, yy, cand, closest):
+        b, l, _ = cand.shape
+        n = X.shape[0]
+        rows = np.zeros((b, l, n), dtype=np.float32)
+        if n:
+            for r in range(b):
+                dd = O._euclidean_distances_sq_f32(cand[r].numpy(), X.numpy())
+                if closest is not None:
+                    np.minimum(closest[r].numpy()[None, :], dd, out=dd)
+                rows[r] = dd
+        return torch.from_numpy(rows), torch.from_numpy(rows.astype(np.float64).sum(axis=2))
+
+
+def _seed_case():
+    X = datagen.make_encodings(31, 1201, 16, 7, 1500, 900)
+    return np.ascontiguousarray(X - X.mean(axis=0))
+
+
+def _seed_worker(rank, world, port, out_dir):
+    sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pccs_accel import dist as pdist
+    from pccs_accel import seeding
+    Xc = _seed_case()
+    n, k, b = Xc.shape[0], 12, 3
+    rs = np.random.RandomState(17)
+    draws = [seeding.draw(rs, n, k) for _ in range(b)]
+    lo, hi = pdist.shard_bounds(n, rank, world)
+    centers, indices = seeding.kmeans_plusplus_sharded(torch.from_numpy(Xc[lo:hi].copy()), lo, n, k, draws,
+                                                       ops=NumpySeedOps())
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), centers=centers.numpy(), indices=indices.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_seeding_matches_oracle(world, tmp_path):
+    """k-means++ over row-sharded points (ranks' cumulative-sum offsets, counted draws, exchanged candidate
+    rows, all-reduced potentials): every rank ends with the seeds sklearn's algorithm picks, restart by
+    restart, from the same RandomState stream."""
+    mp.spawn(_seed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    Xc = _seed_case()
+    rs = np.random.RandomState(17)
+    want = [O.kmeans_plusplus(Xc, 12, rs) for _ in range(3)]
+    parts = [np.load(tmp_path / f"s{r}.npz") for r in range(world)]
+    for p in parts:
+        assert np.array_equal(p["indices"], parts[0]["indices"]) and np.array_equal(p["centers"], parts[0]["centers"])
+        for r in range(3):
+            assert np.array_equal(p["indices"][r], want[r][1])
+            assert np.array_equal(p["centers"][r], want[r][0])
+
+
+def _fit_worker(rank, world, port, out_dir):
+    sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pccs_accel import dist as pdist
+    X = _fit_case()
+    lo, hi = pdist.shard_bounds(X.shape[0], rank, world)
+    stats = (lambda A: A.double().sum(dim=0), lambda A, m: ((A.double() - m) ** 2).sum(dim=0),
+             lambda A, v: A.sub_(v))
+    fit = pdist.kmeans_fit_sharded(torch.from_numpy(X[lo:hi].copy()), X.shape[0], row_offset=lo, n_clusters=9, n_init=4,
+                                   random_state=5, lloyd_ops=NumpyOps(), seed_ops=NumpySeedOps(), stats=stats)
+    np.savez(os.path.join(out_dir, f"f{rank}.npz"), labels=fit["labels"].numpy(), centers=fit["centers"].numpy(),
+             inertia=fit["inertia"], n_iter=fit["n_iter"])
+    dist.destroy_process_group()
+
+
+def _fit_case():
+    return np.ascontiguousarray(datagen.make_encodings(41, 901, 16, 9, 1500, 900))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_full_fit_matches_oracle(world, tmp_path):
+    """KMeans(n_clusters, n_init=4, random_state=5).fit over sharded points: global mean / tolerance, sharded
+    k-means++ for all restarts, ShardedLloyd per restart, sklearn's best-restart rule with the sharded
+    same-clustering check -- the oracle's labels, iteration count and inertia."""
+    mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    X = _fit_case()
+    want = O.kmeans_fit(X, 9, n_init=4, random_state=5)
+    parts = [np.load(tmp_path / f"f{r}.npz") for r in range(world)]
+    labels = np.concatenate([p["labels"] for p in parts])
+    assert np.array_equal(labels, want["labels"])
+    for p in parts:
+        assert int(p["n_iter"]) == want["n_iter"]
+        assert np.allclose(p["centers"], want["centers"], rtol=1e-5, atol=1e-6)
+        assert np.isclose(float(p["inertia"]), want["inertia"], rtol=1e-6)
+
+
+def test_same_clustering_sharded_single_process():
+    sys.path.insert(0, PKG_DIR)
+    from pccs_accel.dist import is_same_clustering_sharded
+    a = torch.tensor([0, 1, 2, 1, 0, 2], dtype=torch.int32)
+    assert is_same_clustering_sharded(a, torch.tensor([2, 0, 1, 0, 2, 1], dtype=torch.int32), 3, False)
+    assert not is_same_clustering_sharded(a, torch.tensor([2, 0, 1, 1, 2, 1], dtype=torch.int32), 3, False)
+    assert is_same_clustering_sharded(a[:0], a[:0], 3, False)
+
+
 def test_shard_bounds_cover_everything():
     sys.path.insert(0, PKG_DIR)
     from pccs_accel.dist import shard_bounds

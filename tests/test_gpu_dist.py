@@ -115,3 +115,64 @@ def test_rccl_one_rank_collectives(which, tmp_path, gpu_device):
     assert np.array_equal(p["labels"], single["labels"].cpu().numpy())
     assert np.allclose(p["centers"], single["centers"].cpu().numpy(), rtol=1e-6, atol=1e-7)
     assert np.isclose(float(p["inertia"]), single["inertia"], rtol=1e-9)
+
+
+def _pp_case():
+    X = datagen.make_encodings(51, 6007, 96, 24, 1500, 900)
+    return np.ascontiguousarray(X)
+
+
+def _pp_worker(rank, world, port, backend, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(120, exit=True)
+    sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "tests", "golden")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pccs_accel import dist as pdist
+    from pccs_accel import seeding
+    X = _pp_case()
+    n, k, b = X.shape[0], 24, 5
+    lo, hi = pdist.shard_bounds(n, rank, world)
+    Xl = torch.from_numpy(X[lo:hi].copy()).to(dev)
+    # seeding alone, on data centred with the global mean (what the fit passes it)
+    Xc = torch.from_numpy((X - X.mean(axis=0, dtype=np.float64).astype(np.float32))[lo:hi].copy()).to(dev)
+    rs = np.random.RandomState(23)
+    draws = [seeding.draw(rs, n, k) for _ in range(b)]
+    centers, indices = seeding.kmeans_plusplus_sharded(Xc, lo, n, k, draws, force_collectives=True)
+    fit = pdist.kmeans_fit_sharded(Xl, n, row_offset=lo, n_clusters=k, n_init=b, random_state=23, force_collectives=True)
+    np.savez(os.path.join(out_dir, f"p{rank}.npz"), seed_centers=centers.cpu().numpy(), seed_indices=indices.cpu().numpy(),
+             labels=fit["labels"].cpu().numpy(), centers=fit["centers"].cpu().numpy(), inertia=fit["inertia"],
+             n_iter=fit["n_iter"])
+    dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+
+
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("gloo", 3), ("nccl", 1)])
+def test_sharded_seeding_and_full_fit_match_single_gpu(backend, world, tmp_path, gpu_device):
+    """k-means++ and the whole KMeans(n_clusters, n_init).fit over row-sharded points with the real kernels
+    (mtp_kpp_candidate_dists_f32 + the step-level Lloyd entries) against the one-GPU path: same seeds for every
+    restart, same labels / iteration count, centres and inertia to rounding."""
+    from pccs_accel import clustering, seeding
+    mp.spawn(_pp_worker, args=(world, _free_port(), backend, str(tmp_path)), nprocs=world, join=True)
+    X = _pp_case()
+    n, k, b = X.shape[0], 24, 5
+    Xc = torch.from_numpy(X - X.mean(axis=0, dtype=np.float64).astype(np.float32)).to(gpu_device)
+    rs = np.random.RandomState(23)
+    draws = [seeding.draw(rs, n, k) for _ in range(b)]
+    c1, i1 = seeding.kmeans_plusplus_batched(Xc, k, draws)
+    single = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), k, n_init=b, random_state=23)
+    parts = [np.load(tmp_path / f"p{r}.npz") for r in range(world)]
+    for p in parts:
+        assert np.array_equal(p["seed_indices"], i1.cpu().numpy())
+        assert np.array_equal(p["seed_centers"], c1.cpu().numpy())
+        assert int(p["n_iter"]) == single["n_iter"]
+        assert np.allclose(p["centers"], single["centers"].cpu().numpy(), rtol=1e-6, atol=1e-7)
+        assert np.isclose(float(p["inertia"]), single["inertia"], rtol=1e-9)
+    assert np.array_equal(np.concatenate([p["labels"] for p in parts]), single["labels"].cpu().numpy())
