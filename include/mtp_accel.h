@@ -193,8 +193,16 @@ int mtp_kmeans_plusplus_batched_f32(const float *X, int64_t n, int d, int k, int
  *     for the n_cand (<= 8) candidate rows cand[b, l, :] of each of `batch` restarts and this rank's n
  *     points (closest == NULL: no minimum, the first centre), and pot_out[b, l] = sum_i rows_out[b, l, i]
  *     (double; the rank-local part of sklearn's candidates_pot).  d must be a multiple of 16.
- *     ws: mtp_kpp_candidate_dists_workspace_bytes(n, d, batch) bytes. */
+ *     ws: mtp_kpp_candidate_dists_workspace_bytes(n, d, batch) bytes.
+ *   mtp_kpp_count_below_f32: counts[b, j] = #{ i : closest[b, 0] + ... + closest[b, i] < thresholds[b, j] }
+ *     (double sums) = np.searchsorted(stable_cumsum(closest[b]), thresholds[b, j]) on this rank's rows
+ *     (_kmeans.py:234-238); with the thresholds shifted by the lower ranks' totals, the ranks' counts add
+ *     up to the candidate id.  closest [batch, n] float, thresholds [batch, l] double, counts [batch, l]
+ *     int64, l <= 16.  ws: mtp_kpp_count_below_workspace_bytes(n, batch) bytes. */
 int64_t mtp_kpp_candidate_dists_workspace_bytes(int64_t n, int d, int batch);
+int64_t mtp_kpp_count_below_workspace_bytes(int64_t n, int batch);
+int mtp_kpp_count_below_f32(const float *closest, int64_t n, int batch, const double *thresholds, int l,
+                            int64_t *counts, void *ws, size_t ws_bytes, void *stream);
 int mtp_kpp_row_sqnorm_f64(const float *X, int64_t n, int d, double *yy, void *stream);
 int mtp_kpp_candidate_dists_f32(const float *X, int64_t n, int d, const double *yy, const float *cand, int batch,
                                 int n_cand, const float *closest, float *rows_out, double *pot_out, void *ws,

@@ -988,3 +988,133 @@ extern "C" int mtp_kpp_candidate_dists_f32(const float *X, int64_t n, int d, con
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// counts[b, l] = #{ i : closest[b, 0] + ... + closest[b, i] < thresholds[b, l] }  (sums in double)
+// = np.searchsorted(stable_cumsum(closest[b]), thresholds[b, l]) on this rank's rows.  With the
+// thresholds shifted by the lower ranks' totals, the sum of the ranks' counts is the candidate id
+// sklearn draws (cluster/_kmeans.py:234-238) -- without materialising the cumulative sum.
+// Two launches: block sums (128 points each), then per restart one workgroup: prefix of the block
+// sums, block of the crossing, one in-block scan per threshold (k_kpp_select's scheme).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_kpp_block_sums(const float *__restrict__ closest, int64_t n, int64_t nblk,
+                                                        double *bsum) {
+    __shared__ double part[2];
+    const float *row = closest + (size_t)blockIdx.y * n;
+    const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    double v = i < n ? (double)row[i] : 0.0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[(size_t)blockIdx.y * nblk + blockIdx.x] = part[0] + part[1];
+}
+
+__global__ __launch_bounds__(1024) void k_kpp_count_below(const float *__restrict__ closest, int64_t n, int64_t nblk,
+                                                          const double *__restrict__ bsum, double *prefix,
+                                                          const double *__restrict__ thresholds, int l_count,
+                                                          int64_t *counts) {
+    __shared__ double red[16];
+    __shared__ double s_thr[KPP_MAX_L];
+    __shared__ int s_blk[KPP_MAX_L];
+    __shared__ double s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *row = closest + (size_t)blockIdx.x * n;
+    const double *bs = bsum + (size_t)blockIdx.x * nblk;
+    prefix += (size_t)blockIdx.x * nblk;
+    thresholds += (size_t)blockIdx.x * l_count;
+    counts += (size_t)blockIdx.x * l_count;
+    if (tid < l_count) {
+        s_thr[tid] = thresholds[tid];
+        s_blk[tid] = 0;
+    }
+    if (tid == 0) s_carry = 0.0;
+    __syncthreads();
+    // inclusive prefix of the block sums, chunks of 1024 with a running carry; per threshold the
+    // number of blocks whose prefix is still below it (= index of the block of the crossing)
+    for (int64_t b0 = 0; b0 < nblk; b0 += 1024) {
+        const int64_t b = b0 + tid;
+        double v = b < nblk ? bs[b] : 0.0;
+        for (int o = 1; o < 64; o <<= 1) {
+            const double t = __shfl_up(v, o);
+            if (lane >= o) v += t;
+        }
+        if (lane == 63) red[wave] = v;
+        __syncthreads();
+        double woff = 0.0;
+        for (int w = 0; w < wave; ++w) woff += red[w];
+        v += woff + s_carry;
+        if (b < nblk) {
+            prefix[b] = v;
+            for (int l = 0; l < l_count; ++l)
+                if (v < s_thr[l]) atomicAdd(&s_blk[l], 1);
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = v;
+        __syncthreads();
+    }
+    // one wave per threshold: two points per lane of its block, first cumulative sum >= threshold
+    for (int l = wave; l < l_count; l += 16) {
+        const int blk = s_blk[l];
+        int64_t cnt = n;  // every cumulative sum is below the threshold
+        if (blk < nblk) {
+            const double start = blk > 0 ? prefix[blk - 1] : 0.0;
+            const int64_t p0 = (int64_t)blk * 128 + lane * 2;
+            const double a0 = p0 < n ? (double)row[p0] : 0.0;
+            const double a1 = p0 + 1 < n ? (double)row[p0 + 1] : 0.0;
+            const double s2 = a0 + a1;
+            double incl = s2;
+            for (int o = 1; o < 64; o <<= 1) {
+                const double t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const double excl = start + (incl - s2);
+            int first = 2;
+            if (excl + s2 >= s_thr[l]) first = 1;
+            if (excl + a0 >= s_thr[l]) first = 0;
+            const unsigned long long mask = __ballot(first < 2);
+            int64_t cid;
+            if (mask) {
+                const int wl = (int)__builtin_ctzll(mask);
+                cid = (int64_t)blk * 128 + wl * 2 + __shfl(first, wl);
+            } else {
+                cid = (int64_t)(blk + 1) * 128;  // rounding put the threshold past this block's end
+            }
+            cnt = cid < n ? cid : n;
+        }
+        if (lane == 0) counts[l] = cnt;
+    }
+}
+
+extern "C" int64_t mtp_kpp_count_below_workspace_bytes(int64_t n, int batch) {
+    if (n <= 0 || batch <= 0) return 0;
+    const int64_t nblk = (n + 127) / 128;
+    return (int64_t)(2 * kpp_align((size_t)batch * nblk * sizeof(double)));
+}
+
+extern "C" int mtp_kpp_count_below_f32(const float *closest, int64_t n, int batch, const double *thresholds, int l,
+                                       int64_t *counts, void *ws, size_t ws_bytes, void *stream) {
+    MTP_REQUIRE(n >= 0 && batch >= 1 && batch <= 65535, "mtp_kpp_count_below: bad shape n=%lld batch=%d", (long long)n, batch);
+    MTP_REQUIRE(l >= 1 && l <= KPP_MAX_L, "mtp_kpp_count_below: 1..%d thresholds per restart (got %d)", KPP_MAX_L, l);
+    MTP_REQUIRE(thresholds && counts, "mtp_kpp_count_below: null pointer");
+    hipStream_t s = mtp_stream(stream);
+    if (n == 0) {
+        MTP_HIP(hipMemsetAsync(counts, 0, (size_t)batch * l * sizeof(int64_t), s));
+        return MTP_OK;
+    }
+    MTP_REQUIRE(closest && ws, "mtp_kpp_count_below: null pointer");
+    const int64_t nblk = (n + 127) / 128;
+    MTP_REQUIRE(nblk <= 0x7fffffff, "mtp_kpp_count_below: n too large");
+    const size_t need = (size_t)mtp_kpp_count_below_workspace_bytes(n, batch);
+    if (ws_bytes < need) {
+        mtp_set_error("mtp_kpp_count_below: workspace of %zu bytes, need %zu", ws_bytes, need);
+        return MTP_E_WORKSPACE;
+    }
+    double *bsum = static_cast<double *>(ws);
+    double *prefix = reinterpret_cast<double *>(static_cast<char *>(ws) + kpp_align((size_t)batch * nblk * sizeof(double)));
+    hipLaunchKernelGGL(k_kpp_block_sums, dim3((unsigned)nblk, (unsigned)batch), dim3(128), 0, s, closest, n, nblk, bsum);
+    MTP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_kpp_count_below, dim3(batch), dim3(1024), 0, s, closest, n, nblk, bsum, prefix, thresholds, l, counts);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}

@@ -46,6 +46,8 @@ SIGNATURES = {
     "mtp_kmeans_plusplus_batched_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mtp_kmeans_plusplus_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mtp_kpp_candidate_dists_workspace_bytes": (_i64, [_i64, _i32, _i32]),
+    "mtp_kpp_count_below_workspace_bytes": (_i64, [_i64, _i32]),
+    "mtp_kpp_count_below_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     "mtp_kpp_row_sqnorm_f64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "mtp_kpp_candidate_dists_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mtp_best_of_k_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -126,6 +126,21 @@ class DeviceSeedOps:
         return rows, pot
 
 
+    def count_below(self, closest, thresholds):
+        """counts int64 [B, L]: this rank's cumulative sums of closest[b] (double) below thresholds[b, l]."""
+        b, n = closest.shape
+        l = thresholds.shape[1]
+        dev = closest.device
+        counts = torch.empty((b, l), dtype=torch.int64, device=dev)
+        ws_bytes = max(int(lib().mtp_kpp_count_below_workspace_bytes(max(n, 1), b)), 256)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        thresholds = thresholds.contiguous()
+        with torch.cuda.device(dev):
+            check(lib().mtp_kpp_count_below_f32(ptr(closest), n, b, ptr(thresholds), l, ptr(counts), ptr(ws), ws_bytes,
+                                                stream_ptr()), "mtp_kpp_count_below_f32")
+        return counts
+
+
 def _first_argmin(v):
     """np.argmin along dim 1: the FIRST minimum."""
     l = v.shape[1]
@@ -140,9 +155,10 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
     step over ROW-SHARDED centred points: this rank holds rows [row_offset, row_offset + n_local) of
     the n_total.  ``draws``: one ``draw()`` result per restart, identical on every rank.
 
-    Per new centre: (1) every rank's cumulative sum of its closest-distance rows; the ranks' totals
-    are all-gathered and give each rank its offset into the global ``stable_cumsum``; (2) the number
-    of cumulative sums below each draw is counted locally (searchsorted) and all-reduced: the sum IS
+    Per new centre: (1) the ranks' totals of their closest-distance rows (= their part of the chosen
+    candidate's potential) are all-gathered and give each rank its offset into the global
+    ``stable_cumsum``; (2) the number of local cumulative sums below each draw is counted
+    (``mtp_kpp_count_below_f32``, no cumulative sum is materialised) and all-reduced: the sum IS
     sklearn's ``searchsorted(cumsum, rand)``; (3) the owners contribute the candidate rows to one
     all-reduce; (4) each rank computes the candidates' distances to its points with the fp64
     matrix-pipe kernel and its part of the potentials; one all-reduce of [B, L] doubles; (5) every
@@ -175,6 +191,7 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
     yy = ops.row_sqnorm(X_local)
     indices = torch.empty((b, n_clusters), dtype=torch.int64, device=dev)
     rows, pot = ops.candidate_dists(X_local, yy, fetch_rows(ids0[:, None]), None)
+    local_tot = pot[:, 0].clone()  # this rank's part of the potential = the total of its closest row
     if collective:
         pdist.all_reduce_sum(pot, group)
     closest = rows[:, 0, :].contiguous()
@@ -184,21 +201,21 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
         u = torch.from_numpy(np.ascontiguousarray(np.stack([uu for _, uu in draws]))).to(dev)  # [B, K-1, L]
     for c in range(1, n_clusters):
         rand = u[:, c - 1, :] * cur_pot.to(torch.float64)[:, None]
-        cs = torch.cumsum(closest.to(torch.float64), dim=1)
         if collective:
-            tot = cs[:, -1].contiguous() if n_local else torch.zeros(b, dtype=torch.float64, device=dev)
-            every = pdist.all_gather_cat(tot[None], ws, group)  # [W, B]
-            cs = cs + every[:rank].sum(dim=0)[:, None]
-        cnt = torch.searchsorted(cs, rand.contiguous())  # cumulative sums < draw, per (restart, trial)
+            every = pdist.all_gather_cat(local_tot[None].contiguous(), ws, group)  # [W, B]
+            rand = rand - every[:rank].sum(dim=0)[:, None]  # the draw relative to this rank's first row
+        cnt = ops.count_below(closest, rand)  # cumulative sums < draw, per (restart, trial)
         if collective:
             pdist.all_reduce_sum(cnt, group)
         idx = cnt.clamp(max=n_total - 1)
         rows, pot = ops.candidate_dists(X_local, yy, fetch_rows(idx), closest)
+        pot_local = pot.clone() if collective else pot
         if collective:
             pdist.all_reduce_sum(pot, group)
         pot32 = pot.to(torch.float32)
         best = _first_argmin(pot32)
         closest = rows[ar, best].contiguous()
         cur_pot = pot32[ar, best]
+        local_tot = pot_local[ar, best]
         indices[:, c] = idx[ar, best]
     return fetch_rows(indices), indices

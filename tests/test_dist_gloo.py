@@ -263,6 +263,13 @@ class NumpySeedOps:
     def row_sqnorm(self, X):
         return torch.zeros(max(X.shape[0], 1), dtype=torch.float64)
 
+    def count_below(self, closest, thresholds):
+        c = closest.numpy()
+        out = np.zeros(thresholds.shape, dtype=np.int64)
+        for r in range(c.shape[0]):
+            out[r] = np.searchsorted(np.cumsum(c[r], dtype=np.float64), thresholds[r].numpy())
+        return torch.from_numpy(out)
+
     def candidate_dists(self, X, yy, cand, closest):
         b, l, _ = cand.shape
         n = X.shape[0]

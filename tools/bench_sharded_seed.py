@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Per-step cost of the sharded k-means++ driver at the 8-GPU shard size (development measurement):
+N/8 = 1.25M points, D = 128, 20 restarts, 8 local trials (K = 1024), the first 33 centres, on ONE GPU
+(world size 1: no exchange; add ~4 small collectives per step on a node)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "modular-trajectory-prediction-toolkit_amd"))
+sys.path.insert(0, ROOT)
+from bench import make_encodings  # noqa: E402
+from pccs_accel import kernels as K  # noqa: E402
+from pccs_accel import seeding  # noqa: E402
+
+dev = torch.device("cuda:0")
+n, d, k_full, b = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000, 128, 1024, 20
+X = make_encodings(n, d, k_full, seed=1000, device=dev)
+K.sub_rowvec_(X, (K.col_sums(X) / n).to(torch.float32))
+rs = np.random.RandomState(0)
+draws = [seeding.draw(rs, n, k_full) for _ in range(b)]
+for k in (5, 33):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    c, i = seeding.kmeans_plusplus_sharded(X, 0, n, k, draws)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if k == 33:
+        flop = 2.0 * n * d * b * 8 * (k - 1)
+        print(json.dumps({"n_local": n, "d": d, "restarts": b, "local_trials": 8, "centres": k, "s": dt,
+                          "ms_per_step": dt / (k - 1) * 1e3, "fp64_TFLOP/s_incl_overheads": flop / dt / 1e12,
+                          "full_seeding_of_1024_centres_s": dt / (k - 1) * 1023}))
