@@ -180,10 +180,13 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
 
     def fetch_rows(idx):
         """X[idx] for GLOBAL row indices idx [B, m] -> [B, m, D] on every rank (owners contribute, one all-reduce)."""
-        own = (idx >= lo) & (idx < hi)
-        rows = torch.zeros(idx.shape + (d,), dtype=torch.float32, device=dev)
         if n_local:
-            rows[own] = X_local[(idx[own] - lo)]
+            # gather with clamped local indices and zero the rows of other ranks: no boolean-mask
+            # indexing, which would cost a host synchronisation per call
+            own = (idx >= lo) & (idx < hi)
+            rows = X_local[(idx - lo).clamp(0, n_local - 1)] * own[..., None].to(torch.float32)
+        else:
+            rows = torch.zeros(idx.shape + (d,), dtype=torch.float32, device=dev)
         if collective:
             pdist.all_reduce_sum(rows, group)
         return rows
