@@ -122,10 +122,20 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
 
     if batch is None:
         batch = restart_batch(n, d, n_clusters, n_init)
-    if init_is_array or batch <= 1:
-        for _ in range(n_init):
-            c0 = c_init if init_is_array else seeding.kmeans_plusplus(Xc, n_clusters, rs)[0]
-            consider(*K.lloyd(Xc, c0, max_iter=max_iter, tol_abs=tol_abs, check_every=check_every))
+    if init_is_array:
+        consider(*K.lloyd(Xc, c_init, max_iter=max_iter, tol_abs=tol_abs, check_every=check_every))
+    elif batch <= 1:
+        # Lloyd one restart at a time, but the restarts are still SEEDED in groups: with one restart
+        # half of the seeding kernel's 16-row candidate tile is empty.  Same seeds as one by one
+        # (the draws are made up front in sklearn's order; seeding consumes the stream, Lloyd does not).
+        draws = [seeding.draw(rs, n, n_clusters) for _ in range(n_init)]
+        l = 2 + int(np.log(n_clusters))
+        group = int(max(1, min(n_init, 16e9 // (2.0 * l * n * 4))))  # closest-distance rows: 2 * L * N floats each
+        for s0 in range(0, n_init, group):
+            c0s, _ = seeding.kmeans_plusplus_batched(Xc, n_clusters, draws[s0:s0 + group])
+            for b in range(c0s.shape[0]):
+                consider(*K.lloyd(Xc, c0s[b].contiguous(), max_iter=max_iter, tol_abs=tol_abs, check_every=check_every))
+            del c0s
     else:
         # the draws of every restart, in sklearn's order (seeding consumes the stream, Lloyd does not)
         draws = [seeding.draw(rs, n, n_clusters) for _ in range(n_init)]

@@ -82,6 +82,9 @@ def kmeans_plusplus_batched(Xc, n_clusters, draws):
     ids = np.asarray([c for c, _ in draws], dtype=np.int64)
     if ids.min() < 0 or ids.max() >= n:
         raise ValueError("first-centre index out of range")
+    if n_clusters > 1 and any(tuple(u.shape) != (n_clusters - 1, l) for _, u in draws):
+        # the kernel strides through the draws as [B, K-1, L]: anything else would be mis-indexed silently
+        raise ValueError(f"every restart's uniform draws must have shape ({n_clusters - 1}, {l})")
     ids_dev = torch.from_numpy(ids).to(dev)
     u_dev = None
     if n_clusters > 1:
@@ -176,6 +179,8 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
     ids0 = torch.tensor([c for c, _ in draws], dtype=torch.int64, device=dev)
     if int(ids0.min()) < 0 or int(ids0.max()) >= n_total:
         raise ValueError("first-centre index out of range")
+    if n_clusters > 1 and any(u.shape[0] < n_clusters - 1 or u.shape[1] != draws[0][1].shape[1] for _, u in draws):
+        raise ValueError("every restart needs at least n_clusters - 1 rows of uniform draws of one width")
     ar = torch.arange(b, device=dev)
 
     def fetch_rows(idx):
