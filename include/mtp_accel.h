@@ -93,6 +93,13 @@ int mtp_centroid_sums_f32(const float *X, int64_t n, int d, const int32_t *label
 int mtp_cluster_means_f32(const double *sums, const double *counts, int k, int d, float *means,
                           int32_t *n_empty_out, void *stream);
 
+/* Classifier targets from the cluster labels, the hand-off of PCCSNet/train_steps.py:357 and :364-366:
+ * labels_long[i] = (int64) labels[i]  (torch.from_numpy(cluster_result).long(), the PCCS_Dataset.cluster_results of
+ * PCCSNet/models/auxiliary.py:101-107) and one_hot[i, c] = (c == labels[i]) as float [n, k], every element written
+ * (gt_prob = torch.zeros(n, k); gt_prob[range(n), cluster_result] = 1).  Either output may be NULL.
+ * Labels must lie in [0, k) (the reference raises IndexError otherwise; the host side checks). */
+int mtp_label_targets_f32(const int32_t *labels, int64_t n, int k, int64_t *labels_long, float *one_hot, void *stream);
+
 /* Inertia: *inertia += sum_i ||x_i - c_{labels[i]}||^2 (per-point term in float with
  * sklearn's grouping, sum in double).  Replaces sklearn cluster/_k_means_common.pyx:94-124.
  * per_point may be NULL; otherwise receives the n per-point squared distances. */

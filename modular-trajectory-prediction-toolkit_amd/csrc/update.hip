@@ -600,3 +600,53 @@ extern "C" int mtp_apply_relocation_f32(double *red, int k, int d, int m, const 
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Classifier targets from the cluster labels (PCCSNet/train_steps.py:357, :364-366):
+//   labels_long[i] = (int64) labels[i]                       torch.from_numpy(cluster_result).long()
+//   one_hot[i, c]  = (c == labels[i]) ? 1 : 0   float [n, k] gt_prob = zeros; gt_prob[range(n), cluster_result] = 1
+// HBM-bound: n*k*4 bytes written once (every element, so the buffer needs no zeroing), 16 B per lane.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_label_targets(const int32_t *__restrict__ labels, int64_t n, int k,
+                                                       int64_t *labels_long, float *one_hot) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (labels_long != nullptr)
+        for (int64_t i = t0; i < n; i += stride) labels_long[i] = (int64_t)labels[i];
+    if (one_hot == nullptr) return;
+    if ((k & 3) == 0) {
+        const int kq = k >> 2;
+        const int64_t total = n * kq;
+        float4 *out = reinterpret_cast<float4 *>(one_hot);
+        for (int64_t e = t0; e < total; e += stride) {
+            const int64_t i = e / kq;
+            const int c = (int)(e - i * kq) * 4;
+            const int lab = labels[i];
+            out[e] = make_float4(lab == c ? 1.f : 0.f, lab == c + 1 ? 1.f : 0.f, lab == c + 2 ? 1.f : 0.f,
+                                 lab == c + 3 ? 1.f : 0.f);
+        }
+    } else {
+        const int64_t total = n * k;
+        for (int64_t e = t0; e < total; e += stride) {
+            const int64_t i = e / k;
+            one_hot[e] = (labels[i] == (int)(e - i * k)) ? 1.f : 0.f;
+        }
+    }
+}
+
+extern "C" int mtp_label_targets_f32(const int32_t *labels, int64_t n, int k, int64_t *labels_long, float *one_hot,
+                                     void *stream) {
+    MTP_REQUIRE(n >= 0 && k >= 1, "mtp_label_targets: bad shape n=%lld k=%d", (long long)n, k);
+    if (n == 0 || (labels_long == nullptr && one_hot == nullptr)) return MTP_OK;
+    MTP_REQUIRE(labels != nullptr, "mtp_label_targets: labels is NULL");
+    MTP_REQUIRE(one_hot == nullptr || (k & 3) != 0 || reinterpret_cast<uintptr_t>(one_hot) % 16 == 0,
+                "mtp_label_targets: one_hot must be 16-byte aligned");
+    const int64_t work = one_hot != nullptr ? ((k & 3) == 0 ? n * (k >> 2) : n * k) : n;
+    int64_t blocks = (work + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_label_targets, dim3((unsigned)blocks), dim3(256), 0, mtp_stream(stream), labels, n, k, labels_long,
+                       one_hot);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mtp_assign_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mtp_centroid_sums_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
     "mtp_cluster_means_f32": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "mtp_label_targets_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "mtp_inertia_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mtp_lloyd_begin_f32": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mtp_lloyd_estep_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),

@@ -221,6 +221,26 @@ def get_memory_data(dataset, save_dir, args):
     return memory_data, cluster_result, size_array
 
 
+def classifier_targets(cluster_result, n_cluster, device=None, one_hot=True):
+    """The label hand-off of PCCSNet/train_steps.py:357 and :364-366 in one launch.
+
+    ``cluster_result``: the int labels ``get_memory_data`` / ``cluster_data`` return (NumPy array or tensor).
+    Returns ``(cluster_results, gt_prob)``: ``torch.from_numpy(cluster_result).long()`` -- what the reference stores
+    in ``train_set.cluster_results`` -- and, when ``one_hot`` (the reference's ``--disable_modality_loss`` branch),
+    ``gt_prob`` float32 [N, n_cluster] with ``gt_prob[i, cluster_result[i]] = 1`` (else None), both on the device.
+    Out-of-range labels raise IndexError like the reference's fancy index."""
+    if isinstance(cluster_result, torch.Tensor):
+        lab = cluster_result
+    else:
+        lab = torch.from_numpy(np.ascontiguousarray(cluster_result))
+    if lab.dim() != 1:
+        raise ValueError(f"Expected a 1D label array, got shape {tuple(lab.shape)}")
+    if device is None:
+        device = lab.device if lab.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    lab = lab.to(device=device, dtype=torch.int32).contiguous()
+    return K.label_targets(lab, int(n_cluster), want_long=True, want_one_hot=one_hot)
+
+
 def get_modality(memory_data, cluster_result, num_cluster):
     """PCCSNet/utils/utility.py:98-105: per-cluster mean of the member rows -> float32 [K, D].
 

@@ -126,6 +126,20 @@ def cluster_means(sums, counts):
     return means, n_empty
 
 
+def label_targets(labels, k, want_long=True, want_one_hot=True):
+    """(labels int64 [N] or None, one-hot float32 [N, K] or None) on labels' device, for int32 device labels in [0, K)."""
+    _req(labels, "labels", torch.int32, 1, align=4)
+    n = labels.shape[0]
+    if n and (int(labels.min()) < 0 or int(labels.max()) >= k):  # the reference's fancy index raises IndexError here
+        raise IndexError(f"cluster label out of range for {k} clusters")
+    dev = labels.device
+    lab64 = torch.empty(n, dtype=torch.int64, device=dev) if want_long else None
+    hot = torch.empty((n, k), dtype=torch.float32, device=dev) if want_one_hot else None
+    with torch.cuda.device(dev):
+        check(lib().mtp_label_targets_f32(ptr(labels), n, k, ptr(lab64), ptr(hot), stream_ptr()), "mtp_label_targets_f32")
+    return lab64, hot
+
+
 def inertia(X, C, labels, per_point=False):
     _req(X, "X", torch.float32, 2)
     _req(C, "C", torch.float32, 2)

@@ -319,12 +319,27 @@ def gen_g12():
          dense=dense)
 
 
+def gen_g13():
+    # PCCSNet/train_steps.py:357 and :364-366 are inline statements of train() (which needs a GPU): the label
+    # hand-off is evaluated here with the reference's own torch expressions on a small label vector.
+    import torch
+    rng = np.random.default_rng(61)
+    n, k = 53, 12
+    cluster_result = rng.integers(0, k, size=n).astype(np.int32)
+    cluster_result[:3] = [0, k - 1, 0]
+    cluster_results = torch.from_numpy(cluster_result).long()
+    gt_prob = torch.zeros(n, k)
+    gt_prob[list(range(n)), cluster_result] = 1
+    save("g13_classifier_targets", n=n, k=k, cluster_result=cluster_result, cluster_results=cluster_results.numpy(),
+         gt_prob=gt_prob.numpy())
+
+
 if __name__ == "__main__":
     warnings.simplefilter("error")  # a ConvergenceWarning here means a bad fixture
     utility, metrics = _import_ref("PCCSNet")
     only = sys.argv[1:]
     jobs = dict(g1=lambda: gen_g1(utility), g2=lambda: gen_g2(utility), g45=gen_g4_g5,
-                g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12)
+                g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, g13=gen_g13)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

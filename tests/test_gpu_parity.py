@@ -411,3 +411,30 @@ def test_kmeans_fit_rejects_non_finite_input_like_sklearn(gpu_device):
         kmeans_fit(X, 4, n_init=1)
     with pytest.raises(ValueError, match="should be >= n_clusters"):
         kmeans_fit(X[:3].contiguous(), 4, n_init=1)
+
+
+@pytest.mark.parametrize("n,k", [(53, 12), (1, 1), (4097, 200), (1000, 7), (0, 5)])
+def test_classifier_targets_match_reference_expression(n, k, gpu_device):
+    """mtp_label_targets_f32 behind classifier_targets: int64 labels and the one-hot [N, K] targets of
+    PCCSNet/train_steps.py:357, :364-366 -- bit-exact against the fixture made with the reference's own torch
+    expressions and against the oracle on other shapes (k % 4 != 0, empty)."""
+    from pccs_accel.clustering import classifier_targets
+    if (n, k) == (53, 12):
+        g = load_golden("g13_classifier_targets")
+        labels, want_long, want_hot = g["cluster_result"], g["cluster_results"], g["gt_prob"]
+    else:
+        labels = np.random.default_rng(n + k).integers(0, k, size=n).astype(np.int32)
+        want_long, want_hot = O.classifier_targets(labels, k)
+    lab64, hot = classifier_targets(labels, k, device=gpu_device)
+    assert lab64.dtype == torch.int64 and np.array_equal(lab64.cpu().numpy(), want_long)
+    assert hot.dtype == torch.float32 and tuple(hot.shape) == (n, k) and np.array_equal(hot.cpu().numpy(), want_hot)
+    lab_only, none = classifier_targets(torch.from_numpy(labels).to(gpu_device), k, one_hot=False)
+    assert none is None and np.array_equal(lab_only.cpu().numpy(), want_long)
+
+
+def test_classifier_targets_reject_out_of_range_labels(gpu_device):
+    from pccs_accel.clustering import classifier_targets
+    with pytest.raises(IndexError):
+        classifier_targets(np.array([0, 3, 1], dtype=np.int32), 3, device=gpu_device)
+    with pytest.raises(IndexError):
+        classifier_targets(np.array([0, -1], dtype=np.int32), 3, device=gpu_device)
