@@ -307,6 +307,23 @@ def main():
                          "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ebytes / (ms_eval * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                          "traffic": traffic.get("k_best_of_k") if (args.eval_n, args.eval_k, args.eval_t) == (1_000_000, 100, 12) else None,
                          "ms_per_launch": ms_eval, "algorithmic_bytes_per_launch": ebytes}}
+        # CPU baseline of this half beside it (rank 0, N = 1 only): the oracle's C restatement of the per-agent
+        # loop (train_steps.py:214-232), a scalar single-thread port, on a bounded sample of the same trajectories
+        if world == 1 and not args.no_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import kmeans_oracle as O
+            ns = min(1_000_000, ehi - elo)
+            ph, gh = pred[:ns].cpu().numpy(), gt[:ns].cpu().numpy()
+            t0 = time.perf_counter()
+            o = O.best_of_k(ph, gh, mode=0)
+            cdt = time.perf_counter() - t0
+            g = K.best_of_k(pred[:ns], gt[:ns], mode=0)
+            out["best_of_k"]["cpu_baseline"] = {
+                "value": ns * float(args.eval_k) / cdt, "unit": "traj/s", "cores": 1, "kind": "port",
+                "sample": f"oracle.c best-of-K (scalar, one thread) on the first {ns} agents, mode 0; {cdt:.2f} s"}
+            out["best_of_k"]["parity"] = {
+                "sample_agents": int(ns), "argmin_mismatches_vs_cpu_oracle": int((g["idx"].cpu().numpy() != o["idx"]).sum()),
+                "max_rel_err_min_ade": float(np.max(np.abs(g["min_ade"].cpu().numpy() - o["min_ade"]) / np.maximum(o["min_ade"], 1e-30)))}
         del pred, gt
 
     # ---- CPU baseline on a bounded sample (rank 0, N = 1 only) ----

@@ -24,6 +24,8 @@ if __name__ == "__main__":
     ap.add_argument("--n-init", type=int, default=20)
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--cpu-n-init", type=int, default=4, help="restarts of the sklearn run (time is scaled to --n-init)")
+    ap.add_argument("--cpu-threads", default="", help="comma list of thread counts for extra sklearn runs "
+                    "(the reference pins OMP_NUM_THREADS=8, PCCSNet/utils/utility.py:8)")
     args = ap.parse_args()
     from pccs_accel import clustering, seeding
     from pccs_accel import kernels as K
@@ -70,3 +72,12 @@ if __name__ == "__main__":
             t_cpu = (time.perf_counter() - t0) * args.n_init / args.cpu_n_init
             print(f"   sklearn CPU fit {t_cpu:.2f} s for n_init={args.n_init} (measured on {args.cpu_n_init} restarts, scaled; "
                   f"inertia {km.inertia_:.2f}, n_iter {km.n_iter_}) -> speedup {t_cpu/t_fit:.1f}x", flush=True)
+            for nt in [int(x) for x in args.cpu_threads.split(",") if x]:
+                from threadpoolctl import threadpool_limits
+                with threadpool_limits(limits=nt):
+                    np.random.seed(0)
+                    t0 = time.perf_counter()
+                    KMeans(n_clusters=k, n_init=args.cpu_n_init).fit(Xh)
+                    t_nt = (time.perf_counter() - t0) * args.n_init / args.cpu_n_init
+                print(f"   sklearn CPU fit at {nt} threads: {t_nt:.2f} s for n_init={args.n_init} -> speedup {t_nt/t_fit:.1f}x",
+                      flush=True)
