@@ -95,6 +95,26 @@ def test_lloyd_fullsize_decreases_inertia(big, gpu_device):
     del Xc
 
 
+def test_seeding_fullsize_sharded_equals_fused(big, gpu_device):
+    """k-means++ at the 8-GPU shard size (1.25M rows of the big matrix, 4 restarts, 8 local trials): the step-level
+    sharded driver (candidate distances + count-below entries, here with one rank and no exchange) must pick the
+    seeds of the fused one-GPU path, and the seeds must be valid distinct rows."""
+    from pccs_accel import kernels as KK
+    from pccs_accel import seeding
+    X, _ = big
+    n, k = 1_250_000, 17
+    Xc = X[:n].clone()
+    KK.sub_rowvec_(Xc, (KK.col_sums(Xc) / n).to(torch.float32))
+    rs = np.random.RandomState(3)
+    draws = [(c, np.ascontiguousarray(u[:k - 1])) for c, u in (seeding.draw(rs, n, K) for _ in range(4))]
+    c_f, i_f = seeding.kmeans_plusplus_batched(Xc, k, draws)
+    c_s, i_s = seeding.kmeans_plusplus_sharded(Xc, 0, n, k, draws)
+    assert torch.equal(i_f, i_s) and torch.equal(c_f, c_s)
+    idx = i_f.cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < n and all(len(set(r)) == k for r in idx)
+    assert torch.equal(c_f[2], Xc[i_f[2]])
+
+
 def test_best_of_k_fullsize_properties(gpu_device):
     from pccs_accel import kernels as Kn
     n, k, t = 1_000_000, 100, 12
