@@ -640,6 +640,7 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
         index_out += index_stride * b;
     }
     __shared__ double red[16];
+    __shared__ double red_l[KPP_MAX_L][16];
     __shared__ float pots[KPP_MAX_L];
     __shared__ int s_sel;
     __shared__ double s_rand[KPP_MAX_L];
@@ -647,20 +648,21 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
     __shared__ double s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // (1) potentials
+    // (1) potentials: per candidate a thread-strided partial, a wave tree, then the 16 wave sums in order
+    // (one barrier for all candidates; the additions and their order are those of a per-candidate loop)
     for (int l = 0; l < n_prev; ++l) {
         double v = 0.0;
         for (int64_t b = tid; b < nblk; b += 1024) v += bsum_cur[(size_t)l * nblk + b];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red[wave] = v;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-            for (int w = 0; w < 16; ++w) t += red[w];
-            pots[l] = (float)t;
-        }
-        __syncthreads();
+        if (lane == 0) red_l[l][wave] = v;
     }
+    __syncthreads();
+    if (tid < n_prev) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red_l[tid][w];
+        pots[tid] = (float)t;
+    }
+    __syncthreads();
     if (tid == 0) {
         int best = 0;
         for (int l = 1; l < n_prev; ++l)
@@ -697,10 +699,10 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
         for (int w = 0; w < wave; ++w) woff += red[w];
         const double carry = s_carry;
         v += woff + carry;
-        if (b < nblk) {
-            prefix[b] = v;
-            for (int l = 0; l < n_new; ++l)
-                if (v < s_rand[l]) atomicAdd(&s_blk[l], 1);
+        if (b < nblk) prefix[b] = v;
+        for (int l = 0; l < n_new; ++l) {  // one LDS atomic per wave and candidate
+            const unsigned long long below = __ballot(b < nblk && v < s_rand[l]);
+            if (lane == 0 && below) atomicAdd(&s_blk[l], (int)__popcll(below));
         }
         __syncthreads();
         if (tid == 1023) s_carry = v;
@@ -892,21 +894,20 @@ __global__ __launch_bounds__(64) void k_kpp_stage_cands(const float *__restrict_
 // potentials of the candidate rows = sums of their block sums, in k_kpp_select's order
 __global__ __launch_bounds__(1024) void k_kpp_potentials(const double *__restrict__ bsum, int64_t nblk, int n_cand,
                                                          double *pot) {
-    __shared__ double red[16];
+    __shared__ double red_l[8][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *bs = bsum + (size_t)blockIdx.x * 8 * nblk;
     for (int l = 0; l < n_cand; ++l) {
         double v = 0.0;
         for (int64_t b = tid; b < nblk; b += 1024) v += bs[(size_t)l * nblk + b];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red[wave] = v;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-            for (int w = 0; w < 16; ++w) t += red[w];
-            pot[(size_t)blockIdx.x * n_cand + l] = t;
-        }
-        __syncthreads();
+        if (lane == 0) red_l[l][wave] = v;
+    }
+    __syncthreads();
+    if (tid < n_cand) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red_l[tid][w];
+        pot[(size_t)blockIdx.x * n_cand + tid] = t;
     }
 }
 
@@ -1044,10 +1045,10 @@ __global__ __launch_bounds__(1024) void k_kpp_count_below(const float *__restric
         double woff = 0.0;
         for (int w = 0; w < wave; ++w) woff += red[w];
         v += woff + s_carry;
-        if (b < nblk) {
-            prefix[b] = v;
-            for (int l = 0; l < l_count; ++l)
-                if (v < s_thr[l]) atomicAdd(&s_blk[l], 1);
+        if (b < nblk) prefix[b] = v;
+        for (int l = 0; l < l_count; ++l) {  // one LDS atomic per wave and threshold
+            const unsigned long long below = __ballot(b < nblk && v < s_thr[l]);
+            if (lane == 0 && below) atomicAdd(&s_blk[l], (int)__popcll(below));
         }
         __syncthreads();
         if (tid == 1023) s_carry = v;
