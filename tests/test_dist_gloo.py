@@ -139,7 +139,7 @@ def _case(which):
     return Xc, C0, float(O.tolerance(X))
 
 
-def _worker(rank, world, port, which, check_every, out_dir, fixed_steps=0):
+def _worker(rank, world, port, which, check_every, out_dir, fixed_steps=0, max_iter=300):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -151,10 +151,10 @@ def _worker(rank, world, port, which, check_every, out_dir, fixed_steps=0):
                             ops=NumpyOps())
     extra = {}
     if fixed_steps:  # the first iterations with the flags read one step late (what bench.py times)
-        n_reloc, noop, attempts, state = sl.run_fixed(fixed_steps, tol, 300)
+        n_reloc, noop, attempts, state = sl.run_fixed(fixed_steps, tol, max_iter)
         extra = dict(n_reloc=n_reloc, n_noop=len(noop), attempts=attempts, state=state,
                      iters_after_fixed=int(sl.read_flags()[1]))
-    labels, inertia, centers, n_iter = sl.run(max_iter=300, tol_abs=tol, check_every=check_every)
+    labels, inertia, centers, n_iter = sl.run(max_iter=max_iter, tol_abs=tol, check_every=check_every)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), labels=labels.numpy(), centers=centers.numpy(), inertia=inertia,
              n_iter=n_iter, lo=lo, hi=hi, **extra)
     dist.destroy_process_group()
@@ -208,6 +208,23 @@ def test_lagged_flag_checks_match_oracle(which, world, fixed_steps, tmp_path):
         if which == "relocate":
             assert int(p["n_reloc"]) >= 1
     assert np.array_equal(labels, ol)
+    assert np.allclose(parts[0]["centers"], oc, rtol=1e-5, atol=1e-6)
+    assert np.isclose(float(parts[0]["inertia"]), oi, rtol=1e-6)
+
+
+@pytest.mark.parametrize("which", ["plain", "relocate"])
+def test_lagged_flag_checks_stop_at_max_iter(which, tmp_path):
+    """max_iter reached inside run_fixed: the loop state becomes MAXITER (4), the attempt enqueued behind it is a
+    recorded no-op, and run() only adds the final E-step -- the oracle's max_iter=3 result."""
+    mp.spawn(_worker, args=(2, _free_port(), which, 1, str(tmp_path), 10, 3), nprocs=2, join=True)
+    Xc, C0, tol = _case(which)
+    ol, oi, oc, on = O.kmeans_single_lloyd(Xc, C0, 3, tol)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(2)]
+    assert on == 3
+    for p in parts:
+        assert int(p["n_iter"]) == 3 and int(p["iters_after_fixed"]) == 3 and int(p["state"]) == 4
+        assert int(p["attempts"]) - int(p["n_noop"]) == 3
+    assert np.array_equal(np.concatenate([p["labels"] for p in parts]), ol)
     assert np.allclose(parts[0]["centers"], oc, rtol=1e-5, atol=1e-6)
     assert np.isclose(float(parts[0]["inertia"]), oi, rtol=1e-6)
 
