@@ -106,12 +106,7 @@ static int launch_assign_mfma(const float *X, int64_t n, const float *staged, in
     // than 4 waves x 64 points at 2 waves/SIMD (tools/assign_tune.hip, N=10M K=1024 D=128)
     constexpr int PT = 1, CTW = 2, WPB = 8, WPS = 4;
     const size_t lds = 2 * (size_t)CTW * mtp_tile_floats(D) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        MTP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign_mfma<D, PT, CTW, WPB, WPS, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    MTP_SET_MAX_LDS_ONCE((&k_assign_mfma<D, PT, CTW, WPB, WPS, true>), lds);
     const int64_t pts_per_block = WPB * 32 * PT;
     const int64_t blocks = (n + pts_per_block - 1) / pts_per_block;
     MTP_REQUIRE(blocks <= 0x7fffffff, "mtp_assign: n too large");
@@ -136,12 +131,7 @@ int mtp_launch_assign(const float *X, int64_t n, int d, const float *C, const fl
     MTP_REQUIRE(d >= 1 && d <= 1024, "mtp_assign: generic kernel supports 1 <= d <= 1024 (got %d)", d);
     MTP_REQUIRE(C != nullptr && c2 != nullptr, "mtp_assign: generic kernel needs C and c2");
     const size_t lds = 32 * (size_t)d * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        MTP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign_generic),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024 * 4));
-        attr_set = true;
-    }
+    MTP_SET_MAX_LDS_ONCE(&k_assign_generic, 32 * 1024 * 4);
     const int64_t blocks = (n + 255) / 256;
     MTP_REQUIRE(blocks <= 0x7fffffff, "mtp_assign: n too large");
     hipLaunchKernelGGL(k_assign_generic, dim3((unsigned)blocks), dim3(256), lds, s, X, n, d, C, c2, k, labels,

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -28,6 +29,23 @@ void mtp_set_error(const char *fmt, ...);
     } while (0)
 
 #define MTP_LAUNCH_CHECK() MTP_HIP(hipGetLastError())
+
+constexpr int MTP_MAX_DEVICES = 64;  // per-device host state (function attributes, symbol addresses) is kept for this many
+
+// hipFuncSetAttribute acts on the CURRENT device's function object: done once per device (not once per
+// process), safe from several host threads.  `func` in parentheses when it holds template commas.
+#define MTP_SET_MAX_LDS_ONCE(func, bytes)                                                                       \
+    do {                                                                                                        \
+        static std::atomic<unsigned char> done_[MTP_MAX_DEVICES];                                               \
+        int dev_ = 0;                                                                                           \
+        MTP_HIP(hipGetDevice(&dev_));                                                                           \
+        const bool track_ = dev_ >= 0 && dev_ < MTP_MAX_DEVICES;                                                \
+        if (!track_ || !done_[dev_].load(std::memory_order_acquire)) {                                          \
+            MTP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(func),                                   \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));             \
+            if (track_) done_[dev_].store(1, std::memory_order_release);                                        \
+        }                                                                                                       \
+    } while (0)
 
 // ------------------------------------------------------------------------------------------
 // Staged centroid image (what the MFMA E-step streams through LDS).

@@ -162,12 +162,7 @@ extern "C" int mtp_soft_labels_f64(const int64_t *offsets, const int64_t *ids, c
     if (n == 0) return MTP_OK;
     MTP_REQUIRE(offsets && labels && dense, "mtp_soft_labels: null pointer");
     MTP_REQUIRE((n + 3) / 4 <= 0x7fffffff, "mtp_soft_labels: n too large");
-    static bool attr_set = false;
-    if (!attr_set) {
-        MTP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_soft_labels),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8192 * 4));
-        attr_set = true;
-    }
+    MTP_SET_MAX_LDS_ONCE(&k_soft_labels, 4 * 8192 * 4);
     hipLaunchKernelGGL(k_soft_labels, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)4 * k * sizeof(int),
                        mtp_stream(stream), offsets, ids, labels, n, k, dense);
     MTP_LAUNCH_CHECK();

@@ -59,12 +59,7 @@ int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *label
     const dim3 grid((unsigned)n_chunks, (unsigned)n_ranges, (unsigned)bs.batch);
 #define MTP_ACC_LAUNCH(LPR)                                                                                        \
     do {                                                                                                           \
-        static bool attr_set = false;                                                                              \
-        if (!attr_set) {                                                                                           \
-            MTP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate<LPR, 4, double, true>),                        \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACC_LDS_BYTES + 1024));   \
-            attr_set = true;                                                                                       \
-        }                                                                                                          \
+        MTP_SET_MAX_LDS_ONCE((&k_accumulate<LPR, 4, double, true>), ACC_LDS_BYTES + 1024);                           \
         hipLaunchKernelGGL((k_accumulate<LPR, 4, double, true>), grid, dim3(1024), lds, s, X, n, d, labels, k, kr, rows_per_chunk,    \
                            sums, counts, state, bs);                                                               \
     } while (0)
