@@ -334,12 +334,65 @@ def gen_g13():
          gt_prob=gt_prob.numpy())
 
 
+G14_CASES = [
+    # name, data seed, n, d, k_true, K, spread, noise, np.random.seed
+    ("g14_fit_eth_n73568_k200", 141, 73568, 96, 120, 200, 1800, 420, 7),
+    ("g14_fit_sdd_n17970_k400", 142, 17970, 96, 150, 400, 1800, 420, 8),
+]
+
+
+def gen_g14(utility, only=None):
+    """The reference's real sizes (PCCSNet/README.md: eth split N=73 568 / K=200, SDD N=17 970 / K=400):
+    ``np.random.seed(s); utility.cluster_data(X, K)`` -- KMeans(K, n_init=20).fit -- with sklearn's two per-restart
+    functions wrapped (outputs recorded, nothing altered; the random stream is consumed exactly as without
+    the wrappers): per restart the k-means++ indices, n_iter, inertia and a digest of the labels, plus the
+    winning restart, the final labels and the sizes."""
+    import zlib
+    import sklearn.cluster._kmeans as skm
+
+    for name, seed, n, d, k_true, K, spread, noise, np_seed in G14_CASES:
+        if only and name not in only:
+            continue
+        X = datagen.make_encodings(seed, n, d, k_true, spread, noise)
+        rec = dict(idx=[], n_iter=[], inertia=[], crc=[], sizes=[])
+        kpp0, lloyd0 = skm._kmeans_plusplus, skm._kmeans_single_lloyd
+
+        def kpp(*a, **kw):
+            centers, indices = kpp0(*a, **kw)
+            rec["idx"].append(np.asarray(indices, dtype=np.int64).copy())
+            return centers, indices
+
+        def lloyd(*a, **kw):
+            labels, inertia, centers, n_iter = lloyd0(*a, **kw)
+            rec["n_iter"].append(n_iter)
+            rec["inertia"].append(float(inertia))
+            rec["crc"].append(zlib.crc32(np.ascontiguousarray(labels, dtype=np.int32).tobytes()))
+            rec["sizes"].append(np.bincount(labels, minlength=K).astype(np.int32))
+            return labels, inertia, centers, n_iter
+
+        skm._kmeans_plusplus, skm._kmeans_single_lloyd = kpp, lloyd
+        try:
+            np.random.seed(np_seed)
+            labels, sizes = utility.cluster_data(X.copy(), K)
+        finally:
+            skm._kmeans_plusplus, skm._kmeans_single_lloyd = kpp0, lloyd0
+        assert len(rec["idx"]) == 20 and len(rec["n_iter"]) == 20
+        crc_final = zlib.crc32(np.ascontiguousarray(labels, dtype=np.int32).tobytes())
+        winner = rec["crc"].index(crc_final)
+        save(name, seed=seed, n=n, d=d, k_true=k_true, K=K, spread=spread, noise=noise, np_seed=np_seed,
+             x_crc=zlib.crc32(X.tobytes()), kpp_indices=np.stack(rec["idx"]), n_iter=np.asarray(rec["n_iter"]),
+             inertia=np.asarray(rec["inertia"]), labels_crc=np.asarray(rec["crc"], dtype=np.int64),
+             restart_sizes=np.stack(rec["sizes"]), winner=winner,
+             labels=labels.astype(np.uint8 if K <= 256 else np.uint16), sizes=sizes)
+
+
 if __name__ == "__main__":
     warnings.simplefilter("error")  # a ConvergenceWarning here means a bad fixture
     utility, metrics = _import_ref("PCCSNet")
     only = sys.argv[1:]
     jobs = dict(g1=lambda: gen_g1(utility), g2=lambda: gen_g2(utility), g45=gen_g4_g5,
-                g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, g13=gen_g13)
+                g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, g13=gen_g13,
+                g14=lambda: gen_g14(utility))
     for name, fn in jobs.items():
         if not only or name in only:
             fn()
