@@ -81,6 +81,19 @@ int mtp_sub_rowvec_f32(float *X, int64_t n, int d, const float *vec, void *strea
 int mtp_assign_f32(const float *X, int64_t n, int d, const float *C, int k, const float *c2, int32_t *labels,
                    double *n_changed, void *ws, size_t ws_bytes, void *stream);
 
+/* mtp_assign_f32 for callers that cannot allocate device memory or bring a workspace (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same result as mtp_assign_f32(..., c2 = NULL, ...): the staged centroid image and
+ * ||c||^2 are written into a buffer of MTP_NOALLOC_SCRATCH_BYTES built into the library (one copy per
+ * GPU, held until the process ends); (k, d) with mtp_assign_workspace_bytes(k, d) above that limit
+ * are refused with MTP_E_WORKSPACE (k = 1024, d = 128 needs 549 KB).  Calls nothing that allocates.
+ * All calls on one GPU share that GPU's buffer: calls that overlap on one GPU (two streams or
+ * threads) race; serialise them.  Nothing has to be cleared between calls: each call rewrites
+ * every byte it reads. */
+#define MTP_NOALLOC_SCRATCH_BYTES (1 << 20)
+int mtp_assign_noalloc_f32(const float *X, int64_t n, int d, const float *C, int k, int32_t *labels,
+                           double *n_changed, void *stream);
+
 /* M-step sums: sums[k, d] += sum of member rows, counts[k] += member count (doubles).
  * Replaces sklearn cluster/_k_means_lloyd.pyx:215-218 + :143-152 and the per-cluster
  * gather of PCCSNet/utils/utility.py:98-104 (get_modality). */

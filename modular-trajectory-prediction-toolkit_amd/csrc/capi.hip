@@ -1,6 +1,7 @@
 // C-ABI entry points of libmtp_accel.so (see include/mtp_accel.h) and the single-GPU Lloyd driver.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "mtp_internal.h"
@@ -88,6 +89,51 @@ extern "C" int mtp_assign_f32(const float *X, int64_t n, int d, const float *C, 
     int rc = mtp_launch_stage_centers(C, k, d, staged, c2w, nullptr, s);
     if (rc != MTP_OK) return rc;
     return mtp_launch_assign(X, n, d, C, staged, c2 ? c2 : c2w, k, labels, n_changed, nullptr, s);
+}
+
+// ---- the one entry point that allocates nothing and takes no workspace (include/mtp_accel.h) ----
+// mtp_assign_f32's scratch -- the staged centroid image and ||c||^2 -- lives in a file-scope device
+// array instead of a caller workspace.  In host code `g_noalloc_scratch` is only a stand-in for the
+// symbol, NOT a device address: the address is looked up once per device with hipGetSymbolAddress
+// (each GPU holds its own copy of the array) and only that pointer is ever handed to a kernel.
+static __device__ __align__(256) unsigned char g_noalloc_scratch[MTP_NOALLOC_SCRATCH_BYTES];
+
+static std::mutex g_noalloc_mutex;
+static void *g_noalloc_ptr[MTP_MAX_DEVICES] = {};  // per device: where that GPU's copy of the array lives
+
+static int noalloc_scratch_ptr(void **out) {
+    int dev = -1;
+    MTP_HIP(hipGetDevice(&dev));
+    MTP_REQUIRE(dev >= 0 && dev < MTP_MAX_DEVICES, "mtp_assign_noalloc: device ordinal %d outside [0, %d)", dev,
+                MTP_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (g_noalloc_ptr[dev] == nullptr) {
+        void *p = nullptr;
+        MTP_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch)));  // the CURRENT device's copy
+        MTP_REQUIRE(p != nullptr && (reinterpret_cast<uintptr_t>(p) & 255) == 0,
+                    "mtp_assign_noalloc: scratch symbol resolved to %p", p);
+        g_noalloc_ptr[dev] = p;
+    }
+    *out = g_noalloc_ptr[dev];
+    return MTP_OK;
+}
+
+extern "C" int mtp_assign_noalloc_f32(const float *X, int64_t n, int d, const float *C, int k, int32_t *labels,
+                                      double *n_changed, void *stream) {
+    MTP_REQUIRE(X && C && labels, "mtp_assign_noalloc: null pointer");
+    MTP_REQUIRE(n >= 0 && d >= 1 && k >= 1, "mtp_assign_noalloc: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
+    const int64_t need = mtp_assign_workspace_bytes(k, d);
+    if (need > (int64_t)MTP_NOALLOC_SCRATCH_BYTES) {
+        mtp_set_error("mtp_assign_noalloc: k=%d, d=%d needs %lld bytes of scratch, the built-in buffer holds %d "
+                      "(use mtp_assign_f32 with a caller workspace)", k, d, (long long)need, MTP_NOALLOC_SCRATCH_BYTES);
+        return MTP_E_WORKSPACE;
+    }
+    void *scratch = nullptr;
+    int rc = noalloc_scratch_ptr(&scratch);
+    if (rc != MTP_OK) return rc;
+    // Every byte the E-step reads of the scratch is rewritten by the staging kernel of this call (all
+    // rows of every padded tile and all k norms), so nothing left by an earlier, larger call is seen.
+    return mtp_assign_f32(X, n, d, C, k, nullptr, labels, n_changed, scratch, MTP_NOALLOC_SCRATCH_BYTES, stream);
 }
 
 extern "C" int mtp_centroid_sums_f32(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,

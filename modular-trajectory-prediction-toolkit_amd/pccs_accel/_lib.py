@@ -26,6 +26,7 @@ SIGNATURES = {
     "mtp_col_sqdev_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "mtp_sub_rowvec_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "mtp_assign_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mtp_assign_noalloc_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
     "mtp_centroid_sums_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),
     "mtp_cluster_means_f32": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "mtp_label_targets_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
