@@ -194,14 +194,31 @@ int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_inout, int 
  * l = 2 + int(ln k) -- and passes u as a DEVICE array.  Only enqueues (2 launches per centre);
  * indices_out[k] (int64) and centers_out[k, d] = X[indices_out] are device arrays.
  * ws: mtp_kpp_workspace_bytes(n, d, l) bytes. */
+/* pot_order: how the float32 potentials (sklearn's candidates_pot / current_pot, _kmeans.py:216, :252) are
+ * summed.  MTP_POT_OPENBLAS: in the float addition order of the reference stack -- NumPy handing
+ * [L, n] @ [n, 1] to OpenBLAS sgemv_t and [1, n] @ [n] to sdot (0.3.29, x86-64 SkylakeX / Haswell kernels) --
+ * so that the draws rand = u * pot, and with them the seeds, are sklearn's bit for bit;
+ * MTP_POT_F64: double sums rounded to float (a draw within ~1e-7 relative of a cumulative-sum boundary can
+ * then pick the neighbouring point). */
+#define MTP_POT_F64 0
+#define MTP_POT_OPENBLAS 1
 int64_t mtp_kpp_workspace_bytes(int64_t n, int d, int l);
 int mtp_kmeans_plusplus_f32(const float *X, int64_t n, int d, int k, int l, int64_t center_id, const double *u,
-                            int64_t *indices_out, float *centers_out, void *ws, size_t ws_bytes, void *stream);
+                            int pot_order, int64_t *indices_out, float *centers_out, void *ws, size_t ws_bytes,
+                            void *stream);
+/* out[j] = sum_i rows[j, i] (float32 rows [l, n], l <= 16) in the float addition order MTP_POT_OPENBLAS stands
+ * for: what ``rows @ numpy.ones((n, 1), float32)`` returns through OpenBLAS 0.3.29's x86-64 sgemv_t kernels
+ * (l >= 2) and ``rows @ numpy.ones(n, float32)`` through sdot (l == 1) -- sklearn's candidates_pot and
+ * current_pot (cluster/_kmeans.py:252, :216).  The seeding entries use the same kernels internally; this
+ * entry exposes them so the order can be checked bit for bit on its own.  ws: *_workspace_bytes(n, l). */
+int64_t mtp_blas_order_rowsums_workspace_bytes(int64_t n, int l);
+int mtp_blas_order_rowsums_f32(const float *rows, int l, int64_t n, float *out, void *ws, size_t ws_bytes,
+                               void *stream);
 /* The same for `batch` restarts sharing every launch: center_ids [batch] int64 (DEVICE), u [batch, k-1, l],
  * indices_out [batch, k], centers_out [batch, k, d]; ws: mtp_kpp_batched_workspace_bytes(n, d, l, batch). */
 int64_t mtp_kpp_batched_workspace_bytes(int64_t n, int d, int l, int batch);
 int mtp_kmeans_plusplus_batched_f32(const float *X, int64_t n, int d, int k, int l, int batch, const int64_t *center_ids,
-                                    const double *u, int64_t *indices_out, float *centers_out, void *ws,
+                                    const double *u, int pot_order, int64_t *indices_out, float *centers_out, void *ws,
                                     size_t ws_bytes, void *stream);
 
 /* Step-level pieces of the same seeding for ROW-SHARDED points (one process per GPU; the host side

@@ -35,6 +35,9 @@ __host__ __device__ __forceinline__ const T *kpp_at(const T *p, size_t stride, i
     return reinterpret_cast<const T *>(reinterpret_cast<const char *>(p) + stride * (size_t)b);
 }
 
+static constexpr int KPP_GB = 4096;  // OpenBLAS sgemv_t block length (NBMAX, kernel/x86_64/sgemv_t_4.c)
+__host__ __device__ inline int64_t kpp_pot_blocks(int64_t n) { return ((n & ~(int64_t)3) + KPP_GB - 1) / KPP_GB; }
+
 struct KppWs {
     double *yy;        // [n]  |y|^2 of the upcast rows (shared by all restarts)
     float *rows;       // [2][L][n] closest-distance rows (ping-pong over steps)
@@ -46,6 +49,7 @@ struct KppWs {
     int64_t *cand;     // [L] candidate ids
     int32_t *state;    // [0] = selected candidate of the current rows
     float *pot;        // [1] current potential (float32 like sklearn's)
+    float *pot_part;   // [L][nb4k] float32 sums of the rows' 4096-point blocks in OpenBLAS order (MTP_POT_OPENBLAS)
     size_t stride;     // bytes from one restart's block to the next
     size_t bytes;      // total for `batch` restarts
 };
@@ -72,6 +76,7 @@ static KppWs kpp_carve(void *ws, int64_t n, int d, int l, int batch) {
     w.cand = static_cast<int64_t *>(take((size_t)l * 8));
     w.state = static_cast<int32_t *>(take(64));
     w.pot = static_cast<float *>(take(64));
+    w.pot_part = static_cast<float *>(take((size_t)l * kpp_pot_blocks(n) * 4 + 4));
     w.stride = off - first;
     w.bytes = first + w.stride * (size_t)batch;
     return w;
@@ -615,6 +620,157 @@ static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const K
     return MTP_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Float32 potentials in the float addition order of the reference stack.  sklearn forms them as
+//   candidates_pot = distance_to_candidates @ sample_weight.reshape(-1, 1)   (cluster/_kmeans.py:252)
+//   current_pot    = closest_dist_sq @ sample_weight                        (:216, first centre only)
+// i.e. NumPy hands [L, n] @ [n, 1] to OpenBLAS sgemv_t and [1, n] @ [n] to sdot; with unit weights the
+// products are exact and only the order of the float additions shows.  The draws are rand = u * pot,
+// so a potential that differs in its last bit moves a draw across a cumulative-sum boundary about once
+// in a few thousand draws at N ~ 7e4 -- enough to change the seeds of one restart in four (measured).
+// The orders below are those of OpenBLAS 0.3.29's x86-64 kernels (SkylakeX / Haswell; independent of the
+// thread count), established against NumPy itself and restated in oracle/oracle.c:
+//   sgemv_t: blocks of 4096 points (the last (n & 4095) - (n & 3)), y += block sum, block by block, then the
+//            n & 3 trailing points as y += ((a0 + a1) + a2).  Rows in groups: fours and a last single row
+//            by an 8-lane kernel (lane l adds points l, l+8, ...; a block whose length has bit 2 set gives
+//            its first four points to lanes 0..3 first; then (l + (l+4)), (h0 + h1) + (h2 + h3)), a pair
+//            (L & 2) by a 4-lane kernel (lane l adds l, l+4, ...; (a0 + a1) + (a2 + a3)).
+//   sdot:    n1 = n & -32 points: 4 accumulators x 16 lanes over the first n1 & -64 (point 64 s + 16 a + l),
+//            folded 16 -> 8 (l + (l+8)), a last chunk of 32 as 4 x 8, ((a0 + a1) + a2) + a3, the 8-lane fold;
+//            the remaining points one by one in double, rounded to float at the end.
+// k_kpp_pot_blocks: one workgroup per (4096-point block, group of RW rows, restart): the block is staged
+// through LDS with coalesced loads, then one lane per accumulator walks its chain.
+// ------------------------------------------------------------------------------------------
+static constexpr int KPP_POT_RW = 4;              // rows per workgroup
+static constexpr int KPP_POT_TS = KPP_GB + 8;     // LDS row pitch: the RW x 8 chain lanes hit distinct banks
+
+__global__ __launch_bounds__(256) void k_kpp_pot_blocks(const float *__restrict__ rows0, int64_t n, int n_rows,
+                                                        size_t bstride, float *part0, int64_t nb) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // KPP_POT_RW x KPP_POT_TS
+    const float *rows = kpp_at(rows0, bstride, blockIdx.z);
+    float *part = kpp_at(part0, bstride, blockIdx.z);
+    const int tid = threadIdx.x;
+    const int64_t m_main = n & ~(int64_t)3;
+    const int64_t off = (int64_t)blockIdx.x * KPP_GB;
+    const int nbk = (int)((m_main - off) < KPP_GB ? (m_main - off) : KPP_GB);
+    const int row_base = blockIdx.y * KPP_POT_RW;
+#pragma unroll
+    for (int r = 0; r < KPP_POT_RW; ++r) {
+        const int row = row_base + r;
+        if (row < n_rows) {
+            const float *src = rows + (size_t)row * n + off;
+#pragma unroll 4
+            for (int i = tid; i < nbk; i += 256) tile[r * KPP_POT_TS + i] = src[i];
+        }
+    }
+    __syncthreads();
+    if (tid >= 8 * KPP_POT_RW) return;
+    const int r = tid >> 3, l8 = tid & 7, row = row_base + r;
+    const int quads = n_rows >> 2;
+    const bool pair = (n_rows & 2) && row >= 4 * quads && row < 4 * quads + 2;
+    const float *x = tile + r * KPP_POT_TS;
+    float acc = 0.f;
+    if (row < n_rows) {
+        if (!pair) {
+            int i = 0;
+            if (nbk & 4) {
+                if (l8 < 4) acc = acc + x[l8];
+                i = 4;
+            }
+#pragma unroll 16
+            for (; i + 8 <= nbk; i += 8) acc = acc + x[i + l8];
+        } else if (l8 < 4) {
+#pragma unroll 16
+            for (int i = 0; i + 4 <= nbk; i += 4) acc = acc + x[i + l8];
+        }
+    }
+    const float o4 = __shfl_down(acc, 4, 8);
+    const float h = pair ? acc : acc + o4;          // lanes 0..3
+    const float t = h + __shfl_down(h, 1, 8);       // lanes 0 and 2: h0 + h1, h2 + h3
+    const float y = t + __shfl_down(t, 2, 8);       // lane 0
+    if (l8 == 0 && row < n_rows) part[(size_t)row * nb + blockIdx.x] = y;
+}
+
+// the first centre's potential (one row per restart) in sdot's order; result -> part[0]
+__global__ __launch_bounds__(64) void k_kpp_pot_sdot(const float *__restrict__ rows0, int64_t n, size_t bstride,
+                                                     float *part0) {
+    const float *x = kpp_at(rows0, bstride, blockIdx.x);
+    float *part = kpp_at(part0, bstride, blockIdx.x);
+    const int lane = threadIdx.x, a = lane >> 4, l = lane & 15;
+    const int64_t n1 = n & ~(int64_t)31, n64 = n1 & ~(int64_t)63;
+    float acc = 0.f;
+    int64_t i = 0;
+    for (; i + 512 <= n64; i += 512) {  // eight independent loads in flight per lane
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = x[i + 64 * e + lane];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = acc + v[e];
+    }
+    for (; i < n64; i += 64) acc = acc + x[i + lane];
+    float w = acc + __shfl_down(acc, 8, 16);  // lanes l < 8 of each accumulator: 16 -> 8
+    if (n64 < n1 && l < 8) w = w + x[n64 + 8 * a + l];
+    const int l7 = lane & 7;
+    const float c = ((__shfl(w, l7) + __shfl(w, 16 + l7)) + __shfl(w, 32 + l7)) + __shfl(w, 48 + l7);
+    const float h = c + __shfl_down(c, 4, 8);
+    const float t = h + __shfl_down(h, 1, 8);
+    const float y = t + __shfl_down(t, 2, 8);
+    if (lane == 0) {
+        double dot = n1 ? (double)y : 0.0;
+        for (int64_t j = n1; j < n; ++j) dot += (double)x[j];
+        part[0] = (float)dot;
+    }
+}
+
+// y[j] = the block sums of row j in order, then the n & 3 trailing points (what k_kpp_select does inline)
+__global__ __launch_bounds__(64) void k_kpp_pot_combine(const float *__restrict__ rows, int64_t n, int n_rows,
+                                                        const float *__restrict__ part, int64_t nb, float *out) {
+    const int j = threadIdx.x;
+    if (j >= n_rows) return;
+    float y = 0.f;
+    for (int64_t b = 0; b < nb; ++b) y = y + part[(size_t)j * nb + b];
+    const int tail_n = (int)(n & 3);
+    const float *tail = rows + (size_t)j * n + (n - tail_n);
+    if (tail_n == 3) y = y + ((tail[0] + tail[1]) + tail[2]);
+    else if (tail_n == 2) y = y + (tail[0] + tail[1]);
+    else if (tail_n == 1) y = y + tail[0];
+    out[j] = y;
+}
+
+extern "C" int64_t mtp_blas_order_rowsums_workspace_bytes(int64_t n, int l) {
+    if (n <= 0 || l <= 0) return 0;
+    return (int64_t)kpp_align((size_t)l * (kpp_pot_blocks(n) + 1) * 4);
+}
+
+extern "C" int mtp_blas_order_rowsums_f32(const float *rows, int l, int64_t n, float *out, void *ws, size_t ws_bytes,
+                                          void *stream) {
+    MTP_REQUIRE(rows && out && ws, "mtp_blas_order_rowsums: null pointer");
+    MTP_REQUIRE(l >= 1 && l <= KPP_MAX_L && n >= 1, "mtp_blas_order_rowsums: bad shape l=%d n=%lld", l, (long long)n);
+    if (ws_bytes < (size_t)mtp_blas_order_rowsums_workspace_bytes(n, l)) {
+        mtp_set_error("mtp_blas_order_rowsums: workspace of %zu bytes, need %lld", ws_bytes,
+                      (long long)mtp_blas_order_rowsums_workspace_bytes(n, l));
+        return MTP_E_WORKSPACE;
+    }
+    hipStream_t s = mtp_stream(stream);
+    float *part = static_cast<float *>(ws);
+    if (l == 1) {
+        hipLaunchKernelGGL(k_kpp_pot_sdot, dim3(1), dim3(64), 0, s, rows, n, (size_t)0, out);
+        MTP_LAUNCH_CHECK();
+        return MTP_OK;
+    }
+    const int64_t nb = kpp_pot_blocks(n);
+    if (nb > 0) {
+        constexpr size_t lds = (size_t)KPP_POT_RW * KPP_POT_TS * sizeof(float);
+        MTP_SET_MAX_LDS_ONCE(&k_kpp_pot_blocks, lds);
+        hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)nb, (unsigned)((l + KPP_POT_RW - 1) / KPP_POT_RW), 1), dim3(256),
+                           lds, s, rows, n, l, (size_t)0, part, nb);
+        MTP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_kpp_pot_combine, dim3(1), dim3(64), 0, s, rows, n, l, part, nb, out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
 // One workgroup of 1024 threads.  (1) potentials of the n_prev candidate rows = sums of their block
 // sums; best = first argmin (float32 compare like np.argmin on the float32 potentials); record the
 // chosen centre.  (2) if n_new > 0: draw positions for the next n_new candidates.
@@ -625,9 +781,12 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
                                                      double *prefix, int64_t *cand, double *cand_x, double *cand_xx,
                                                      int32_t *state, float *pot_out, int64_t *index_out,
                                                      size_t bstride, size_t u_stride /* doubles */,
-                                                     size_t index_stride /* int64s */, int ltile) {
+                                                     size_t index_stride /* int64s */, int ltile,
+                                                     const float *pot_part /* NULL: double sums */, int64_t pot_nb,
+                                                     int pot_tail) {
     {
         const int b = blockIdx.x;
+        if (pot_part != nullptr) pot_part = kpp_at(pot_part, bstride, b);
         if (u != nullptr) u += u_stride * b;
         rows_cur = kpp_at(rows_cur, bstride, b);
         bsum_cur = kpp_at(bsum_cur, bstride, b);
@@ -650,17 +809,28 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
 
     // (1) potentials: per candidate a thread-strided partial, a wave tree, then the 16 wave sums in order
     // (one barrier for all candidates; the additions and their order are those of a per-candidate loop)
-    for (int l = 0; l < n_prev; ++l) {
-        double v = 0.0;
-        for (int64_t b = tid; b < nblk; b += 1024) v += bsum_cur[(size_t)l * nblk + b];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red_l[l][wave] = v;
-    }
-    __syncthreads();
-    if (tid < n_prev) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += red_l[tid][w];
-        pots[tid] = (float)t;
+    if (pot_part == nullptr) {
+        for (int l = 0; l < n_prev; ++l) {
+            double v = 0.0;
+            for (int64_t b = tid; b < nblk; b += 1024) v += bsum_cur[(size_t)l * nblk + b];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) red_l[l][wave] = v;
+        }
+        __syncthreads();
+        if (tid < n_prev) {
+            double t = 0.0;
+            for (int w = 0; w < 16; ++w) t += red_l[tid][w];
+            pots[tid] = (float)t;
+        }
+    } else if (tid < n_prev) {
+        // OpenBLAS order (see k_kpp_pot_blocks): y += block sum, block by block, then the n & 3 trailing points
+        float y = 0.f;
+        for (int64_t b = 0; b < pot_nb; ++b) y = y + pot_part[(size_t)tid * pot_nb + b];
+        const float *tail = rows_cur + (size_t)tid * n + (n - pot_tail);
+        if (pot_tail == 3) y = y + ((tail[0] + tail[1]) + tail[2]);
+        else if (pot_tail == 2) y = y + (tail[0] + tail[1]);
+        else if (pot_tail == 1) y = y + tail[0];
+        pots[tid] = y;
     }
     __syncthreads();
     if (tid == 0) {
@@ -793,8 +963,10 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X
 }
 
 static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, int64_t center_id,
-                   const int64_t *center_ids_dev, const double *u, int64_t *indices_out, float *centers_out, void *ws,
-                   size_t ws_bytes, void *stream) {
+                   const int64_t *center_ids_dev, const double *u, int pot_order, int64_t *indices_out,
+                   float *centers_out, void *ws, size_t ws_bytes, void *stream) {
+    MTP_REQUIRE(pot_order == MTP_POT_F64 || pot_order == MTP_POT_OPENBLAS, "mtp_kmeans_plusplus: unknown pot_order %d",
+                pot_order);
     MTP_REQUIRE(X && indices_out && centers_out && ws, "mtp_kmeans_plusplus: null pointer");
     MTP_REQUIRE(n >= 1 && d >= 1 && k >= 1 && k <= n, "mtp_kmeans_plusplus: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
     MTP_REQUIRE(batch >= 1 && batch <= 65535, "mtp_kmeans_plusplus: batch must be in [1, 65535] (got %d)", batch);
@@ -829,16 +1001,37 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
         const int n_new = c < k ? l : 0;
         float *rows_cur = w.rows + (size_t)cur * l * n;
         double *bsum_cur = w.bsum + (size_t)cur * l * nblk;
+        const float *pot_part = nullptr;
+        int64_t pot_nb = 0;
+        int pot_tail = 0;
+        if (pot_order == MTP_POT_OPENBLAS) {
+            pot_part = w.pot_part;
+            if (n_prev == 1) {  // the first centre: [1, n] @ [n] goes to sdot
+                hipLaunchKernelGGL(k_kpp_pot_sdot, dim3(batch), dim3(64), 0, s, rows_cur, n, w.stride, w.pot_part);
+                pot_nb = 1;
+            } else {
+                pot_nb = kpp_pot_blocks(n);
+                pot_tail = (int)(n & 3);
+                if (pot_nb > 0) {
+                    constexpr size_t lds = (size_t)KPP_POT_RW * KPP_POT_TS * sizeof(float);
+                    MTP_SET_MAX_LDS_ONCE(&k_kpp_pot_blocks, lds);
+                    hipLaunchKernelGGL(k_kpp_pot_blocks,
+                                       dim3((unsigned)pot_nb, (unsigned)((n_prev + KPP_POT_RW - 1) / KPP_POT_RW), (unsigned)batch),
+                                       dim3(256), lds, s, rows_cur, n, n_prev, w.stride, w.pot_part, pot_nb);
+                }
+            }
+            MTP_LAUNCH_CHECK();
+        }
         if (tile)
             hipLaunchKernelGGL(k_kpp_select<KPP_TP / 64>, dim3(batch), dim3(1024), 0, s, X, n, d, n_prev, n_new,
                                c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
                                w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1), w.stride, u_stride, (size_t)k,
-                               ltile);
+                               ltile, pot_part, pot_nb, pot_tail);
         else
             hipLaunchKernelGGL(k_kpp_select<KPP_PB / 64>, dim3(batch), dim3(1024), 0, s, X, n, d, n_prev, n_new,
                                c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
                                w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1), w.stride, u_stride, (size_t)k,
-                               ltile);
+                               ltile, pot_part, pot_nb, pot_tail);
         MTP_LAUNCH_CHECK();
         if (c == k) break;
         float *rows_nxt = w.rows + (size_t)(cur ^ 1) * l * n;
@@ -854,16 +1047,17 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
 }
 
 extern "C" int mtp_kmeans_plusplus_f32(const float *X, int64_t n, int d, int k, int l, int64_t center_id,
-                                       const double *u, int64_t *indices_out, float *centers_out, void *ws,
-                                       size_t ws_bytes, void *stream) {
-    return kpp_run(X, n, d, k, l, 1, center_id, nullptr, u, indices_out, centers_out, ws, ws_bytes, stream);
+                                       const double *u, int pot_order, int64_t *indices_out, float *centers_out,
+                                       void *ws, size_t ws_bytes, void *stream) {
+    return kpp_run(X, n, d, k, l, 1, center_id, nullptr, u, pot_order, indices_out, centers_out, ws, ws_bytes, stream);
 }
 
 extern "C" int mtp_kmeans_plusplus_batched_f32(const float *X, int64_t n, int d, int k, int l, int batch,
-                                               const int64_t *center_ids, const double *u, int64_t *indices_out,
-                                               float *centers_out, void *ws, size_t ws_bytes, void *stream) {
+                                               const int64_t *center_ids, const double *u, int pot_order,
+                                               int64_t *indices_out, float *centers_out, void *ws, size_t ws_bytes,
+                                               void *stream) {
     MTP_REQUIRE(center_ids != nullptr, "mtp_kmeans_plusplus_batched: center_ids is NULL");
-    return kpp_run(X, n, d, k, l, batch, 0, center_ids, u, indices_out, centers_out, ws, ws_bytes, stream);
+    return kpp_run(X, n, d, k, l, batch, 0, center_ids, u, pot_order, indices_out, centers_out, ws, ws_bytes, stream);
 }
 
 

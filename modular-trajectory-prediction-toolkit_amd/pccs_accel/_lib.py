@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libmtp_accel.so")
 
 STATE_RUNNING, STATE_STRICT, STATE_TOL, STATE_RELOCATE, STATE_MAXITER = 0, 1, 2, 3, 4
 FLAG_STATE, FLAG_N_ITER, FLAG_N_EMPTY, FLAG_WORDS = 0, 1, 2, 8
+POT_F64, POT_OPENBLAS = 0, 1  # mtp_accel.h MTP_POT_*
 
 _vp, _i64, _i32, _f32, _f64, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_double,
                                     ctypes.c_size_t)
@@ -45,8 +46,10 @@ SIGNATURES = {
                                      ctypes.POINTER(ctypes.c_int), _vp, _sz, _vp]),
     "mtp_kpp_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "mtp_kpp_batched_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32]),
-    "mtp_kmeans_plusplus_batched_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "mtp_kmeans_plusplus_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mtp_kmeans_plusplus_batched_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "mtp_kmeans_plusplus_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "mtp_blas_order_rowsums_workspace_bytes": (_i64, [_i64, _i32]),
+    "mtp_blas_order_rowsums_f32": (_i32, [_vp, _i32, _i64, _vp, _vp, _sz, _vp]),
     "mtp_kpp_candidate_dists_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "mtp_kpp_count_below_workspace_bytes": (_i64, [_i64, _i32]),
     "mtp_kpp_count_below_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),

@@ -67,7 +67,7 @@ def restart_batch(n, d, k, n_init):
 
 
 def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, max_iter=300, tol=1e-4,
-               x_mean=None, check_every=None, batch=None):
+               x_mean=None, check_every=None, batch=None, pot_order="openblas", restarts_out=None):
     """sklearn ``KMeans(n_clusters, n_init=n_init, init=init).fit(X)`` on one MI355X.
 
     X: float32 device tensor [N, D] (not modified).  ``init``: 'k-means++' or a [K, D] array /
@@ -75,7 +75,11 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
     global RandomState, so ``np.random.seed(s)`` before the call pins it, as with the
     reference), an int, or a RandomState.  ``x_mean`` overrides the column mean (tests).
     ``batch``: restarts per launch (default: ``restart_batch``); the result does not depend on it.
-    Returns dict(labels int32 [N] (device), centers float32 [K, D] (device), inertia, n_iter).
+    ``pot_order``: summation order of the k-means++ potentials (``seeding``: "openblas" reproduces the
+    reference stack's seeds, "f64" sums in double).  ``restarts_out``: a list that receives one
+    dict(indices, inertia, n_iter, labels) per restart, in order (tests / diagnostics).
+    Returns dict(labels int32 [N] (device), centers float32 [K, D] (device), inertia, n_iter, tol_abs,
+    x_mean float32 [D] (device): the column mean the points were centred with).
     """
     if not (isinstance(X, torch.Tensor) and X.is_cuda and X.dtype == torch.float32 and X.dim() == 2):
         raise TypeError("kmeans_fit expects a float32 HIP device tensor [N, D]")
@@ -114,9 +118,11 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
 
     best = None
 
-    def consider(labels, inertia, centers, n_iter):
+    def consider(labels, inertia, centers, n_iter, indices=None):
         # sklearn cluster/_kmeans.py:1525-1532, restarts visited in order
         nonlocal best
+        if restarts_out is not None:
+            restarts_out.append(dict(indices=indices, inertia=inertia, n_iter=n_iter, labels=labels))
         if best is None or (inertia < best["inertia"] and not is_same_clustering(labels, best["labels"], n_clusters)):
             best = dict(labels=labels, centers=centers, inertia=inertia, n_iter=n_iter)
 
@@ -132,20 +138,21 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
         l = 2 + int(np.log(n_clusters))
         group = int(max(1, min(n_init, 16e9 // (2.0 * l * n * 4))))  # closest-distance rows: 2 * L * N floats each
         for s0 in range(0, n_init, group):
-            c0s, _ = seeding.kmeans_plusplus_batched(Xc, n_clusters, draws[s0:s0 + group])
+            c0s, idx = seeding.kmeans_plusplus_batched(Xc, n_clusters, draws[s0:s0 + group], pot_order=pot_order)
             for b in range(c0s.shape[0]):
-                consider(*K.lloyd(Xc, c0s[b].contiguous(), max_iter=max_iter, tol_abs=tol_abs, check_every=check_every))
+                consider(*K.lloyd(Xc, c0s[b].contiguous(), max_iter=max_iter, tol_abs=tol_abs, check_every=check_every),
+                         indices=idx[b])
             del c0s
     else:
         # the draws of every restart, in sklearn's order (seeding consumes the stream, Lloyd does not)
         draws = [seeding.draw(rs, n, n_clusters) for _ in range(n_init)]
         for s0 in range(0, n_init, batch):
-            c0s, _ = seeding.kmeans_plusplus_batched(Xc, n_clusters, draws[s0:s0 + batch])
+            c0s, idx = seeding.kmeans_plusplus_batched(Xc, n_clusters, draws[s0:s0 + batch], pot_order=pot_order)
             labels, inertia, centers, n_iter = K.lloyd_batched(Xc, c0s, max_iter=max_iter, tol_abs=tol_abs,
                                                                check_every=check_every or 4)
             inertia = inertia.cpu().numpy()
             for b in range(c0s.shape[0]):
-                consider(labels[b], float(inertia[b]), centers[b], n_iter[b])
+                consider(labels[b], float(inertia[b]), centers[b], n_iter[b], indices=idx[b])
         best["labels"] = best["labels"].clone()
         best["centers"] = best["centers"].clone()
 
@@ -155,6 +162,7 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
         warnings.warn(f"Number of distinct clusters ({distinct}) found smaller than n_clusters ({n_clusters}). "
                       "Possibly due to duplicate points in X.", ConvergenceWarning, stacklevel=2)
     best["tol_abs"] = tol_abs
+    best["x_mean"] = mean32
     return best
 
 

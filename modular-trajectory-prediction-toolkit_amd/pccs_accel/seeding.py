@@ -10,17 +10,28 @@ and the closest-distance rows never leave the device.
 
 Distances follow sklearn.metrics.pairwise._euclidean_distances for float32 input
 (pairwise.py:391-442, :582-653): float64 arithmetic (-2 x.y + ||x||^2 + ||y||^2), float32
-storage, clamped at 0.  Potentials are summed in float64 and rounded to float32 (sklearn's are
-float32 BLAS sums, so a draw that lands within ~1e-6 relative of a cumulative-sum boundary can
-pick the neighbouring point: whole-fit seeded parity is statistical at N ~ 1e5).
+storage, clamped at 0.  The float32 potentials -- sklearn's are BLAS sums (``rows @ sample_weight``), and
+the draws are ``u * pot`` -- are summed in the float addition order of the reference stack (NumPy +
+OpenBLAS 0.3.29 x86-64 kernels: ``pot_order="openblas"``, the default), which makes the seeds sklearn's
+bit for bit at the reference's real sizes (fixture G14); ``pot_order="f64"`` sums in double and rounds
+(then a draw within ~1e-7 relative of a cumulative-sum boundary can pick the neighbouring point: about
+one restart in four gets other seeds at N ~ 7e4).  The sharded seeding uses double sums.
 """
 import numpy as np
 import torch
 
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import POT_F64, POT_OPENBLAS, check, lib, ptr, stream_ptr
+
+POT_ORDERS = {"openblas": POT_OPENBLAS, "f64": POT_F64}
 
 
-def kmeans_plusplus(Xc, n_clusters, random_state, n_local_trials=None):
+def _pot_order(name):
+    if name not in POT_ORDERS:
+        raise ValueError(f"pot_order must be one of {sorted(POT_ORDERS)}, got {name!r}")
+    return POT_ORDERS[name]
+
+
+def kmeans_plusplus(Xc, n_clusters, random_state, n_local_trials=None, pot_order="openblas"):
     """Returns (centers float32 [K, D] device tensor, indices int64 [K] device tensor)."""
     if not (isinstance(Xc, torch.Tensor) and Xc.is_cuda and Xc.dtype == torch.float32 and Xc.dim() == 2
             and Xc.is_contiguous()):
@@ -37,9 +48,26 @@ def kmeans_plusplus(Xc, n_clusters, random_state, n_local_trials=None):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(lib().mtp_kmeans_plusplus_f32(ptr(Xc), n, d, n_clusters, n_local_trials, center_id, ptr(u_dev),
-                                            ptr(indices), ptr(centers), ptr(ws), ws_bytes, stream_ptr()),
+                                            _pot_order(pot_order), ptr(indices), ptr(centers), ptr(ws), ws_bytes,
+                                            stream_ptr()),
               "mtp_kmeans_plusplus_f32")
     return centers, indices
+
+
+def blas_order_rowsums(rows):
+    """float32 [L, n] device rows -> float32 [L]: ``rows @ ones`` in the reference stack's float order
+    (see ``mtp_blas_order_rowsums_f32``); L = 1 follows sdot, L >= 2 sgemv_t."""
+    if not (isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 2
+            and rows.is_contiguous()):
+        raise TypeError("blas_order_rowsums expects a contiguous float32 HIP device tensor [L, n]")
+    l, n = rows.shape
+    out = torch.empty(l, dtype=torch.float32, device=rows.device)
+    ws_bytes = max(int(lib().mtp_blas_order_rowsums_workspace_bytes(n, l)), 256)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=rows.device)
+    with torch.cuda.device(rows.device):
+        check(lib().mtp_blas_order_rowsums_f32(ptr(rows), l, n, ptr(out), ptr(ws), ws_bytes, stream_ptr()),
+              "mtp_blas_order_rowsums_f32")
+    return out
 
 
 _CDF = {}
@@ -68,7 +96,7 @@ def draw(random_state, n, n_clusters, n_local_trials=None):
     return center_id, u
 
 
-def kmeans_plusplus_batched(Xc, n_clusters, draws):
+def kmeans_plusplus_batched(Xc, n_clusters, draws, pot_order="openblas"):
     """Seeding of len(draws) restarts in shared launches.  ``draws``: list of ``draw()`` results,
     one per restart, taken from the RandomState in restart order.  Returns (centers float32
     [B, K, D], indices int64 [B, K]) device tensors."""
@@ -95,8 +123,9 @@ def kmeans_plusplus_batched(Xc, n_clusters, draws):
     ws_bytes = int(lib().mtp_kpp_batched_workspace_bytes(n, d, l, b))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(lib().mtp_kmeans_plusplus_batched_f32(ptr(Xc), n, d, n_clusters, l, b, ptr(ids_dev), ptr(u_dev), ptr(indices),
-                                                    ptr(centers), ptr(ws), ws_bytes, stream_ptr()),
+        check(lib().mtp_kmeans_plusplus_batched_f32(ptr(Xc), n, d, n_clusters, l, b, ptr(ids_dev), ptr(u_dev),
+                                                    _pot_order(pot_order), ptr(indices), ptr(centers), ptr(ws), ws_bytes,
+                                                    stream_ptr()),
               "mtp_kmeans_plusplus_batched_f32")
     return centers, indices
 

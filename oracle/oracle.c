@@ -274,3 +274,89 @@ ORC_ADE_FDE(orc_ade_fde_f64, double)
     }
 ORC_BEST_OF_K(orc_best_of_k_f32, orc_ade_fde_f32, float)
 ORC_BEST_OF_K(orc_best_of_k_f64, orc_ade_fde_f64, double)
+
+/* ------------------------------------------------------------------------------------
+ * Float32 row sums in the order NumPy 2.2 + OpenBLAS 0.3.29 (x86-64 "SkylakeX"/Haswell kernels, the
+ * build container's stack, where the golden fixtures were generated) produce for the two products
+ * sklearn's k-means++ forms with a unit weight vector (sklearn cluster/_kmeans.py:216 and :252):
+ *   candidates_pot = distance_to_candidates @ sample_weight.reshape(-1, 1)   [L, n] @ [n, 1] -> sgemv_t
+ *   current_pot    = closest_dist_sq @ sample_weight                        [1, n] @ [n]    -> sdot
+ * With unit weights every product is exact, so only the ORDER of the float additions matters.  The
+ * orders below were established empirically against numpy (tests/test_oracle_golden.py re-checks them
+ * whenever numpy's BLAS reports the SkylakeX kernels) -- they are independent of the thread count.
+ *
+ * sgemv_t (kernel/x86_64/sgemv_t_4.c): the n points are cut into blocks of 4096 (the last one
+ * (n & 4095) - (n & 3) long), y[j] += block sum for each block in turn, then the n & 3 trailing
+ * points as y[j] += ((a0 + a1) + a2).  Rows are handled in groups: groups of four and a last
+ * single row by an 8-lane kernel, a pair (L & 2) by a 4-lane kernel:
+ *   8-lane: lane l adds points l, l+8, ... in order (when the block length has bit 2 set its first
+ *           four points go to lanes 0..3 first); then (l + (l+4)) for l < 4, then (h0 + h1) + (h2 + h3)
+ *   4-lane: lane l adds points l, l+4, ...; then (a0 + a1) + (a2 + a3)
+ * sdot (kernel/x86_64/sdot.c + sdot_microk_skylakex-2.c): over n1 = n & -32 points: 4 accumulators of
+ * 16 lanes over the first n1 & -64 points (point 64 s + 16 a + l), each folded 16 -> 8 lanes
+ * (l + (l+8)), a remaining chunk of 32 added as 4 x 8, ((a0 + a1) + a2) + a3, the 8-lane fold of
+ * above; the last n - n1 points are added one by one in DOUBLE and the result rounded to float.
+ * ---------------------------------------------------------------------------------- */
+static float fold8(const float *a) {
+    const float h0 = a[0] + a[4], h1 = a[1] + a[5], h2 = a[2] + a[6], h3 = a[3] + a[7];
+    return (h0 + h1) + (h2 + h3);
+}
+
+static float gemv_block8(const float *x, int64_t nb) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t i = 0;
+    if (nb & 4) {
+        for (int l = 0; l < 4; ++l) acc[l] += x[l];
+        i = 4;
+    }
+    for (; i + 8 <= nb; i += 8)
+        for (int l = 0; l < 8; ++l) acc[l] += x[i + l];
+    return fold8(acc);
+}
+
+static float gemv_block4(const float *x, int64_t nb) {
+    float acc[4] = {0, 0, 0, 0};
+    for (int64_t i = 0; i + 4 <= nb; i += 4)
+        for (int l = 0; l < 4; ++l) acc[l] += x[i + l];
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+void orc_rowsums_sgemv_t(const float *rows, int l_rows, int64_t n, float *out) {
+    const int64_t m3 = n & 3, m_main = n - m3;
+    for (int j = 0; j < l_rows; ++j) {
+        const float *x = rows + (size_t)j * n;
+        const int in_pair = (l_rows & 2) && j >= 4 * (l_rows >> 2) && j < 4 * (l_rows >> 2) + 2;
+        float y = 0.0f;
+        for (int64_t off = 0; off < m_main; off += 4096) {
+            const int64_t nb = (m_main - off) < 4096 ? (m_main - off) : 4096;
+            y += in_pair ? gemv_block4(x + off, nb) : gemv_block8(x + off, nb);
+        }
+        if (m3 == 3) y += (x[m_main] + x[m_main + 1]) + x[m_main + 2];
+        else if (m3 == 2) y += x[m_main] + x[m_main + 1];
+        else if (m3 == 1) y += x[m_main];
+        out[j] = y;
+    }
+}
+
+float orc_sum_sdot(const float *x, int64_t n) {
+    const int64_t n1 = n & -32, n64 = n1 & -64;
+    double dot = 0.0;
+    if (n1) {
+        float a8[4][8];
+        float a16[4][16];
+        memset(a16, 0, sizeof(a16));
+        for (int64_t i = 0; i < n64; i += 64)
+            for (int a = 0; a < 4; ++a)
+                for (int l = 0; l < 16; ++l) a16[a][l] += x[i + 16 * a + l];
+        for (int a = 0; a < 4; ++a)
+            for (int l = 0; l < 8; ++l) a8[a][l] = a16[a][l] + a16[a][l + 8];
+        for (int64_t i = n64; i < n1; i += 32)
+            for (int a = 0; a < 4; ++a)
+                for (int l = 0; l < 8; ++l) a8[a][l] += x[i + 8 * a + l];
+        float c[8];
+        for (int l = 0; l < 8; ++l) c[l] = ((a8[0][l] + a8[1][l]) + a8[2][l]) + a8[3][l];
+        dot = (double)fold8(c);
+    }
+    for (int64_t i = n1; i < n; ++i) dot += (double)x[i];
+    return (float)dot;
+}

@@ -346,7 +346,8 @@ def gen_g14(utility, only=None):
     ``np.random.seed(s); utility.cluster_data(X, K)`` -- KMeans(K, n_init=20).fit -- with sklearn's two per-restart
     functions wrapped (outputs recorded, nothing altered; the random stream is consumed exactly as without
     the wrappers): per restart the k-means++ indices, n_iter, inertia and a digest of the labels, plus the
-    winning restart, the final labels and the sizes."""
+    winning restart, the final labels and the sizes -- and, from two repetitions of every restart's Lloyd run,
+    how far sklearn's own outcome moves from run to run (rerun_n_iter, rerun_label_diff)."""
     import zlib
     import sklearn.cluster._kmeans as skm
 
@@ -354,7 +355,7 @@ def gen_g14(utility, only=None):
         if only and name not in only:
             continue
         X = datagen.make_encodings(seed, n, d, k_true, spread, noise)
-        rec = dict(idx=[], n_iter=[], inertia=[], crc=[], sizes=[])
+        rec = dict(idx=[], n_iter=[], inertia=[], crc=[], sizes=[], labels=[])
         kpp0, lloyd0 = skm._kmeans_plusplus, skm._kmeans_single_lloyd
 
         def kpp(*a, **kw):
@@ -368,6 +369,7 @@ def gen_g14(utility, only=None):
             rec["inertia"].append(float(inertia))
             rec["crc"].append(zlib.crc32(np.ascontiguousarray(labels, dtype=np.int32).tobytes()))
             rec["sizes"].append(np.bincount(labels, minlength=K).astype(np.int32))
+            rec["labels"].append(np.array(labels, dtype=np.int32))
             return labels, inertia, centers, n_iter
 
         skm._kmeans_plusplus, skm._kmeans_single_lloyd = kpp, lloyd
@@ -379,10 +381,31 @@ def gen_g14(utility, only=None):
         assert len(rec["idx"]) == 20 and len(rec["n_iter"]) == 20
         crc_final = zlib.crc32(np.ascontiguousarray(labels, dtype=np.int32).tobytes())
         winner = rec["crc"].index(crc_final)
+        # sklearn's own run-to-run spread: its M-step adds per-thread partial sums in lock order
+        # (_k_means_lloyd.pyx:143-152), so repeating the SAME Lloyd run from the same centres gives slightly
+        # different centres, and at N ~ 7e4 other labels on a few points and sometimes another n_iter.
+        # Each restart is repeated twice from its recorded seeds (KMeans(init=X[idx]) centres the init like fit does).
+        from sklearn.cluster import KMeans
+        rerun_n_iter = np.zeros((20, 2), dtype=np.int64)
+        rerun_label_diff = np.zeros((20, 2), dtype=np.int64)
+        rerun_rel_gap = np.zeros((20, 2))  # largest relative distance gap |d_a - d_b| / max(d_a, d_b) of a re-labelled point
+        for r in range(20):
+            for t in range(2):
+                km = KMeans(n_clusters=K, init=X[rec["idx"][r]].copy(), n_init=1).fit(X)
+                rerun_n_iter[r, t] = km.n_iter_
+                mism = np.nonzero(km.labels_ != rec["labels"][r])[0]
+                rerun_label_diff[r, t] = mism.size
+                if mism.size:
+                    C = km.cluster_centers_.astype(np.float64)
+                    x = X[mism].astype(np.float64)
+                    da = ((x - C[km.labels_[mism]]) ** 2).sum(axis=1)
+                    db = ((x - C[rec["labels"][r][mism]]) ** 2).sum(axis=1)
+                    rerun_rel_gap[r, t] = float((np.abs(da - db) / np.maximum(da, db)).max())
         save(name, seed=seed, n=n, d=d, k_true=k_true, K=K, spread=spread, noise=noise, np_seed=np_seed,
              x_crc=zlib.crc32(X.tobytes()), kpp_indices=np.stack(rec["idx"]), n_iter=np.asarray(rec["n_iter"]),
              inertia=np.asarray(rec["inertia"]), labels_crc=np.asarray(rec["crc"], dtype=np.int64),
-             restart_sizes=np.stack(rec["sizes"]), winner=winner,
+             restart_sizes=np.stack(rec["sizes"]), winner=winner, rerun_n_iter=rerun_n_iter,
+             rerun_label_diff=rerun_label_diff, rerun_rel_gap=rerun_rel_gap,
              labels=labels.astype(np.uint8 if K <= 256 else np.uint16), sizes=sizes)
 
 

@@ -331,7 +331,7 @@ def test_sharded_seeding_matches_oracle(world, tmp_path):
     mp.spawn(_seed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     Xc = _seed_case()
     rs = np.random.RandomState(17)
-    want = [O.kmeans_plusplus(Xc, 12, rs) for _ in range(3)]
+    want = [O.kmeans_plusplus(Xc, 12, rs, pot="f64") for _ in range(3)]  # the sharded seeding sums in double
     parts = [np.load(tmp_path / f"s{r}.npz") for r in range(world)]
     for p in parts:
         assert np.array_equal(p["indices"], parts[0]["indices"]) and np.array_equal(p["centers"], parts[0]["centers"])
@@ -368,7 +368,7 @@ def test_sharded_full_fit_matches_oracle(world, tmp_path):
     same-clustering check -- the oracle's labels, iteration count and inertia."""
     mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     X = _fit_case()
-    want = O.kmeans_fit(X, 9, n_init=4, random_state=5)
+    want = O.kmeans_fit(X, 9, n_init=4, random_state=5, pot="f64")
     parts = [np.load(tmp_path / f"f{r}.npz") for r in range(world)]
     labels = np.concatenate([p["labels"] for p in parts])
     assert np.array_equal(labels, want["labels"])

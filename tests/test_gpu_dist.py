@@ -166,8 +166,8 @@ def test_sharded_seeding_and_full_fit_match_single_gpu(backend, world, tmp_path,
     Xc = torch.from_numpy(X - X.mean(axis=0, dtype=np.float64).astype(np.float32)).to(gpu_device)
     rs = np.random.RandomState(23)
     draws = [seeding.draw(rs, n, k) for _ in range(b)]
-    c1, i1 = seeding.kmeans_plusplus_batched(Xc, k, draws)
-    single = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), k, n_init=b, random_state=23)
+    c1, i1 = seeding.kmeans_plusplus_batched(Xc, k, draws, pot_order="f64")  # the sharded seeding sums in double
+    single = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), k, n_init=b, random_state=23, pot_order="f64")
     parts = [np.load(tmp_path / f"p{r}.npz") for r in range(world)]
     for p in parts:
         assert np.array_equal(p["seed_indices"], i1.cpu().numpy())

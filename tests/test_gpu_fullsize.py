@@ -107,7 +107,7 @@ def test_seeding_fullsize_sharded_equals_fused(big, gpu_device):
     KK.sub_rowvec_(Xc, (KK.col_sums(Xc) / n).to(torch.float32))
     rs = np.random.RandomState(3)
     draws = [(c, np.ascontiguousarray(u[:k - 1])) for c, u in (seeding.draw(rs, n, K) for _ in range(4))]
-    c_f, i_f = seeding.kmeans_plusplus_batched(Xc, k, draws)
+    c_f, i_f = seeding.kmeans_plusplus_batched(Xc, k, draws, pot_order="f64")  # the sharded driver sums in double
     c_s, i_s = seeding.kmeans_plusplus_sharded(Xc, 0, n, k, draws)
     assert torch.equal(i_f, i_s) and torch.equal(c_f, c_s)
     idx = i_f.cpu().numpy()
