@@ -159,7 +159,9 @@ int mtp_lloyd_mstep_f32(double *red, const float *C_old, float *C_new, int k, in
  * mtp_far_points_f32: the m points farthest from their assigned (old) centre, by
  * descending ||x - c||^2 (float, direct form), ties to the lowest index:
  *   far_val[m] float, far_idx[m] int64 (row index + idx_offset), far_lab[m] int32,
- *   far_rows[m, d] float.  dist_scratch: n floats. */
+ *   far_rows[m, d] float; entries beyond the number of points are (-1, -1, -1, 0...).
+ *   dist_scratch: mtp_far_points_scratch_bytes(n) bytes (the n distances + the search's partial winners). */
+int64_t mtp_far_points_scratch_bytes(int64_t n);
 int mtp_far_points_f32(const float *X, int64_t n, int d, const float *C_old, const int32_t *labels, int m,
                        int64_t idx_offset, float *far_val, int64_t *far_idx, int32_t *far_lab,
                        float *far_rows, float *dist_scratch, void *stream);
@@ -173,7 +175,7 @@ int mtp_apply_relocation_f32(double *red, int k, int d, int m, const float *far_
  * flags; kernels of iterations enqueued past convergence are no-ops.
  *   C_inout [k, d] initial centres in, final centres out;  labels_out [n]
  *   inertia_out: 1 double (device);  n_iter_out: 1 int (HOST pointer)
- *   ws: mtp_lloyd_workspace_bytes(k, d) + n*4 bytes of device scratch */
+ *   ws: mtp_lloyd_workspace_bytes(k, d) + mtp_far_points_scratch_bytes(n) bytes of device scratch */
 int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int max_iter, double tol_abs,
                   int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, void *ws,
                   size_t ws_bytes, void *stream);

@@ -41,8 +41,6 @@ struct LloydWs {
     float *far_rows;
     size_t bytes;
 };
-static constexpr int MTP_MAX_RELOC = 64;  // empty clusters relocated per iteration, at most
-
 static LloydWs carve_lloyd(void *ws, int k, int d) {
     LloydWs w;
     size_t off = 0;
@@ -57,10 +55,12 @@ static LloydWs carve_lloyd(void *ws, int k, int d) {
     w.c2 = static_cast<float *>(take((size_t)k * 4));
     w.shift = static_cast<float *>(take((size_t)k * 4));
     w.flags = static_cast<int32_t *>(take(MTP_FLAG_WORDS * 4));
-    w.far_val = static_cast<float *>(take(MTP_MAX_RELOC * 4));
-    w.far_idx = static_cast<int64_t *>(take(MTP_MAX_RELOC * 8));
-    w.far_lab = static_cast<int32_t *>(take(MTP_MAX_RELOC * 4));
-    w.far_rows = static_cast<float *>(take((size_t)MTP_MAX_RELOC * d * 4));
+    // one far point per empty cluster, and up to k - 1 clusters can be empty at once
+    // (sklearn _k_means_common.pyx:167-211 relocates every one of them)
+    w.far_val = static_cast<float *>(take((size_t)k * 4));
+    w.far_idx = static_cast<int64_t *>(take((size_t)k * 8));
+    w.far_lab = static_cast<int32_t *>(take((size_t)k * 4));
+    w.far_rows = static_cast<float *>(take((size_t)k * d * 4));
     w.bytes = off;
     return w;
 }
@@ -68,6 +68,12 @@ static LloydWs carve_lloyd(void *ws, int k, int d) {
 extern "C" int64_t mtp_lloyd_workspace_bytes(int k, int d) {
     if (k <= 0 || d <= 0) return 0;
     return (int64_t)carve_lloyd(nullptr, k, d).bytes;
+}
+
+// dist_scratch of mtp_far_points_f32: n per-point distances + the <= 1024 slice winners of each argmax pass
+extern "C" int64_t mtp_far_points_scratch_bytes(int64_t n) {
+    if (n < 0) return 0;
+    return (int64_t)(align_up((size_t)n * 4, 256) + 1024 * 4 + 1024 * 8);
 }
 
 extern "C" int mtp_assign_f32(const float *X, int64_t n, int d, const float *C, int k, const float *c2, int32_t *labels,
@@ -198,7 +204,7 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
     MTP_REQUIRE(n >= k && k >= 1 && d >= 1 && max_iter >= 1, "mtp_lloyd: bad shape n=%lld k=%d d=%d max_iter=%d",
                 (long long)n, k, d, max_iter);
     LloydWs w = carve_lloyd(ws, k, d);
-    const size_t need = w.bytes + (size_t)n * 4;
+    const size_t need = w.bytes + (size_t)mtp_far_points_scratch_bytes(n);
     if (ws_bytes < need) {
         mtp_set_error("mtp_lloyd: workspace of %zu bytes, need %zu", ws_bytes, need);
         return MTP_E_WORKSPACE;
@@ -234,8 +240,7 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
             // iteration `done_iters` (0-based) stopped before its M-step: its E-step ran, labels and
             // red are valid.  The centres it read are in parity (done_iters & 1).
             const int old = done_iters & 1;
-            int m = hflags[MTP_FLAG_N_EMPTY];
-            if (m > MTP_MAX_RELOC) m = MTP_MAX_RELOC;
+            const int m = hflags[MTP_FLAG_N_EMPTY];  // < k: at least one cluster holds points
             rc = mtp_far_points_f32(X, n, d, cbuf[old], labels_out, m, 0, w.far_val, w.far_idx, w.far_lab, w.far_rows,
                                     dist_scratch, stream);
             if (rc != MTP_OK) return rc;
@@ -280,7 +285,7 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
 // iteration is launch-bound; 20 restarts per launch are what makes the fit fast.
 extern "C" int64_t mtp_lloyd_batched_workspace_bytes(int k, int d, int batch, int64_t n) {
     if (k <= 0 || d <= 0 || batch <= 0 || n < 0) return 0;
-    return (int64_t)(carve_lloyd(nullptr, k, d).bytes * (size_t)batch + align_up((size_t)n * 4, 256) +
+    return (int64_t)(carve_lloyd(nullptr, k, d).bytes * (size_t)batch + (size_t)mtp_far_points_scratch_bytes(n) +
                      align_up((size_t)batch * MTP_FLAG_WORDS * 4, 256));
 }
 
@@ -305,7 +310,7 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
         return MTP_E_WORKSPACE;
     }
     float *dist_scratch = reinterpret_cast<float *>(static_cast<char *>(ws) + w.bytes * (size_t)batch);
-    int32_t *flags_packed = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(dist_scratch) + align_up((size_t)n * 4, 256));
+    int32_t *flags_packed = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(dist_scratch) + (size_t)mtp_far_points_scratch_bytes(n));
     hipStream_t s = mtp_stream(stream);
     if (check_every < 1) check_every = 1;
     MtpBatchStride bs;
@@ -358,8 +363,7 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
             if (f[MTP_FLAG_STATE] == MTP_STATE_RELOCATE) {
                 // this restart paused before its M-step: relocate, then redo its M-step alone
                 const int old = f[MTP_FLAG_N_ITER] & 1;
-                int m = f[MTP_FLAG_N_EMPTY];
-                if (m > MTP_MAX_RELOC) m = MTP_MAX_RELOC;
+                const int m = f[MTP_FLAG_N_EMPTY];
                 float *c0 = C_inout + (size_t)b * k * d, *c1 = at(w.c_alt, b);
                 rc = mtp_far_points_f32(X, n, d, old ? c1 : c0, labels_out + (size_t)b * n, m, 0, at(w.far_val, b),
                                         at(w.far_idx, b), at(w.far_lab, b), at(w.far_rows, b), dist_scratch, stream);

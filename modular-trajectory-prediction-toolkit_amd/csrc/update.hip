@@ -444,9 +444,6 @@ extern "C" int mtp_row_sqnorm_f32(const float *A, int64_t n, int d, float *out, 
 // passes (descending distance, ties to the lowest index); a selected point's distance is then
 // set to -1 so that the next pass skips it.
 // ------------------------------------------------------------------------------------------
-static __device__ __align__(256) float g_argmax_pval[1024];
-static __device__ __align__(256) long long g_argmax_pidx[1024];
-
 // (value, index) maximum, ties to the lowest index; index -1 = "nothing yet"
 __device__ __forceinline__ void argmax_merge(float &bv, long long &bi, float ov, long long oi) {
     if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) {
@@ -527,26 +524,20 @@ extern "C" int mtp_far_points_f32(const float *X, int64_t n, int d, const float 
     hipStream_t s = mtp_stream(stream);
     int rc = mtp_launch_inertia(X, n, d, C_old, labels, nullptr, dist_scratch, s);
     if (rc != MTP_OK) return rc;
-    // m argmax passes, each a grid-wide scan (<= 1024 slices) + a one-block merge; the slice
-    // winners live in a file-scope device buffer (one far-point search per device at a time)
-    static float *pval[64] = {nullptr};
-    static long long *pidx[64] = {nullptr};
-    int dev = 0;
-    MTP_HIP(hipGetDevice(&dev));
-    MTP_REQUIRE(dev >= 0 && dev < 64, "mtp_far_points: device index out of range");
-    if (pval[dev] == nullptr) {
-        MTP_HIP(hipGetSymbolAddress(reinterpret_cast<void **>(&pval[dev]), HIP_SYMBOL(g_argmax_pval)));
-        MTP_HIP(hipGetSymbolAddress(reinterpret_cast<void **>(&pidx[dev]), HIP_SYMBOL(g_argmax_pidx)));
-    }
+    // m argmax passes, each a grid-wide scan (<= 1024 slices) + a one-block merge; the slice winners
+    // live behind the n distances in the caller's scratch (mtp_far_points_scratch_bytes), so searches
+    // on different streams do not share anything
+    char *after = reinterpret_cast<char *>(dist_scratch) + ((size_t)n * 4 + 255) / 256 * 256;
+    float *pval = reinterpret_cast<float *>(after);
+    long long *pidx = reinterpret_cast<long long *>(after + 1024 * 4);
     int n_part = (int)((n + 8191) / 8192);
     if (n_part > 1024) n_part = 1024;
     if (n_part < 1) n_part = 1;
     const int64_t per_block = (n + n_part - 1) / n_part;
     for (int p = 0; p < m; ++p) {
-        hipLaunchKernelGGL(k_argmax_partial, dim3(n_part), dim3(1024), 0, s, dist_scratch, n, per_block, pval[dev],
-                           pidx[dev]);
+        hipLaunchKernelGGL(k_argmax_partial, dim3(n_part), dim3(1024), 0, s, dist_scratch, n, per_block, pval, pidx);
         MTP_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(1024), 0, s, dist_scratch, pval[dev], pidx[dev], n_part, p, X, d,
+        hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(1024), 0, s, dist_scratch, pval, pidx, n_part, p, X, d,
                            labels, idx_offset, far_val, far_idx, far_lab, far_rows);
         MTP_LAUNCH_CHECK();
     }
@@ -560,19 +551,18 @@ __global__ __launch_bounds__(256) void k_apply_relocation(double *red, int k, in
     // single block; sequential over the empty clusters like the reference loop (:197-211)
     if (!(far_val[0] > 0.f)) return;  // np.max(distances) == 0: relocating is pointless
     double *counts = red + (size_t)k * d;
-    __shared__ int empties[1024];
-    __shared__ int n_empty;
-    if (threadIdx.x == 0) {
-        int c = 0;
-        for (int j = 0; j < k && c < 1024; ++j)
-            if (counts[j] == 0.0) empties[c++] = j;
-        n_empty = c;
-    }
+    __shared__ int s_new;   // the empty cluster served in this round (ascending id), k = none left
+    if (threadIdx.x == 0) s_new = -1;
     __syncthreads();
-    const int cnt = min(n_empty, m);
-    for (int i = 0; i < cnt; ++i) {
-        const int new_id = empties[i], old_id = far_lab[i];
-        if (old_id < 0) break;
+    for (int i = 0; i < m; ++i) {
+        if (threadIdx.x == 0) {
+            int j = s_new + 1;
+            while (j < k && counts[j] != 0.0) ++j;
+            s_new = j;
+        }
+        __syncthreads();
+        const int new_id = s_new, old_id = far_lab[i];
+        if (new_id >= k || old_id < 0) break;  // uniform: no empty cluster / no far point left
         for (int c = threadIdx.x; c < d; c += blockDim.x) {
             const double x = (double)far_rows[(size_t)i * d + c];
             red[(size_t)old_id * d + c] -= x;
@@ -589,7 +579,7 @@ __global__ __launch_bounds__(256) void k_apply_relocation(double *red, int k, in
 
 extern "C" int mtp_apply_relocation_f32(double *red, int k, int d, int m, const float *far_val, const int32_t *far_lab,
                                         const float *far_rows, void *stream) {
-    MTP_REQUIRE(red && far_val && far_lab && far_rows && m > 0 && m <= 1024, "mtp_apply_relocation: bad arguments");
+    MTP_REQUIRE(red && far_val && far_lab && far_rows && m > 0 && m <= k, "mtp_apply_relocation: bad arguments");
     hipLaunchKernelGGL(k_apply_relocation, dim3(1), dim3(256), 0, mtp_stream(stream), red, k, d, m, far_val, far_lab,
                        far_rows);
     MTP_LAUNCH_CHECK();

@@ -22,9 +22,6 @@ from . import _lib
 from ._lib import (FLAG_N_EMPTY, FLAG_N_ITER, FLAG_STATE, FLAG_WORDS, STATE_RELOCATE, STATE_RUNNING, STATE_STRICT,
                    check, lib, ptr, stream_ptr)
 
-MAX_RELOC = 64
-
-
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -99,7 +96,7 @@ class DeviceOps:
         idx = torch.empty(m, dtype=torch.int64, device=self.device)
         lab = torch.empty(m, dtype=torch.int32, device=self.device)
         rows = torch.empty((m, d), dtype=torch.float32, device=self.device)
-        scratch = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        scratch = torch.empty(int(lib().mtp_far_points_scratch_bytes(n)), dtype=torch.uint8, device=self.device)
         check(lib().mtp_far_points_f32(ptr(X), n, d, ptr(C_old), ptr(labels), m, int(idx_offset), ptr(val), ptr(idx),
                                        ptr(lab), ptr(rows), ptr(scratch), stream_ptr()), "mtp_far_points_f32")
         return val, idx, lab, rows
@@ -274,7 +271,7 @@ class ShardedLloyd:
     def _relocate(self, m, old):
         """Global top-m farthest points -> apply to the (replicated) reduced buffer."""
         o = self.ops
-        m = min(int(m), MAX_RELOC)
+        m = int(m)  # every empty cluster is relocated (sklearn _k_means_common.pyx:167-211)
         self.red.copy_(self.red_backup)  # the paused M-step parked the reduced buffer there
         val, idx, lab, rows = o.far_points(self.X, self.cbuf[old], self.labels, m, self.row_offset)
         if self.collective:

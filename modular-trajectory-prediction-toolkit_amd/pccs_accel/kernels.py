@@ -146,6 +146,8 @@ def inertia(X, C, labels, per_point=False):
     _req(labels, "labels", torch.int32, 1, align=4)
     n, d = X.shape
     assert C.shape[1] == d and labels.numel() == n
+    if n and (int(labels.min()) < 0 or int(labels.max()) >= C.shape[0]):  # the kernel indexes C with these
+        raise IndexError(f"cluster label out of range for {C.shape[0]} centres")
     out = torch.zeros(1, dtype=torch.float64, device=X.device)
     pp = torch.empty(n, dtype=torch.float32, device=X.device) if per_point else None
     with torch.cuda.device(X.device):
@@ -172,7 +174,7 @@ def lloyd(Xc, C0, max_iter=300, tol_abs=0.0, check_every=None):
     C = C0.clone()
     labels = torch.empty(n, dtype=torch.int32, device=Xc.device)
     inert = torch.zeros(1, dtype=torch.float64, device=Xc.device)
-    ws_bytes = int(lib().mtp_lloyd_workspace_bytes(k, d)) + n * 4
+    ws_bytes = int(lib().mtp_lloyd_workspace_bytes(k, d)) + int(lib().mtp_far_points_scratch_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Xc.device)
     n_iter = ctypes.c_int(0)
     with torch.cuda.device(Xc.device):

@@ -24,12 +24,17 @@ def _case(which):
     if which == "plain":
         X = datagen.make_encodings(21, 30011, 96, 50, 1500, 900)   # ragged: not a multiple of anything
         C0 = X[datagen.make_init_indices(7, 30011, 200)].copy()
-    else:  # unreachable centres -> empty clusters -> relocation through the all-gather path
+    elif which == "relocate":  # unreachable centres -> empty clusters -> relocation through the all-gather path
         X = datagen.make_encodings(22, 9001, 128, 12, 2000, 300)
         C0 = X[datagen.make_init_indices(8, 9001, 40)].copy()
         C0[3] = 40.0
         C0[17] = -35.0
         C0[31] = 25.0
+    else:  # "many_empty": 100 of 160 centres unreachable, all relocated in the first iteration (the old cap was 64)
+        X = datagen.make_encodings(23, 7003, 96, 30, 2000, 300)
+        C0 = X[datagen.make_init_indices(9, 7003, 160)].copy()
+        for j in range(100):
+            C0[(3 * j) % 160] = 30.0 + j
     return X, C0
 
 
@@ -61,7 +66,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("which", ["plain", "relocate"])
+@pytest.mark.parametrize("which", ["plain", "relocate", "many_empty"])
 @pytest.mark.parametrize("world,check_every,lagged", [(2, 1, 0), (3, 4, 0), (2, 1, 5), (1, 1, 1000)])
 def test_sharded_device_lloyd_matches_single(which, world, check_every, lagged, tmp_path, gpu_device):
     """lagged > 0: the first iterations go through run_fixed (flags read one step late through
@@ -101,7 +106,7 @@ def _rccl_worker(rank, port, which, out_dir):
     faulthandler.cancel_dump_traceback_later()
 
 
-@pytest.mark.parametrize("which", ["plain", "relocate"])
+@pytest.mark.parametrize("which", ["plain", "relocate", "many_empty"])
 def test_rccl_one_rank_collectives(which, tmp_path, gpu_device):
     """The RCCL ("nccl") backend itself: a one-rank communicator on the box's one GPU, every
     collective of the sharded driver issued on the device buffers (fp64 all-reduce of the packed

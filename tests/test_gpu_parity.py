@@ -241,6 +241,45 @@ def test_relocation_on_mfma_path(gpu_device):
     assert len(np.unique(labels.cpu().numpy())) == 12
 
 
+def test_relocation_of_more_than_64_empty_clusters(gpu_device):
+    """100 of 160 centres start unreachable: sklearn relocates every one of them in the first iteration
+    (_k_means_common.pyx:167-211).  Single run and batched restarts against the oracle -- n_iter, labels,
+    centres -- with the far points handed out by descending distance (sklearn's argpartition order is
+    unspecified), and against sklearn's own order up to a renaming of the relocated clusters."""
+    from pccs_accel import kernels as K
+    n, d, k = 6001, 96, 160
+    X = datagen.make_encodings(91, n, d, 30, 2000, 300)
+    Xc = np.ascontiguousarray(X - X.mean(axis=0))
+    C0 = Xc[datagen.make_init_indices(92, n, k)].copy()
+    for j in range(100):
+        C0[(3 * j) % k] = 30.0 + j
+    tol = float(O.tolerance(X))
+    assert len(np.unique(O.assign(Xc, C0))) <= 60                      # 100 clusters really start empty
+    # exact against the product's documented variant (double sums, far points by descending distance): with 100
+    # rows taken out of float sums the float-sum variant rounds differently enough to re-label a few points of
+    # this far-from-converged start (9 of 6001 here, inertia 2.7e-5 apart) -- it is compared on n_iter / inertia
+    ol, oi, oc, on = O.kmeans_single_lloyd(Xc, C0, 300, tol, far_order="descending", sums="f64")
+    labels, inertia, centers, n_iter = K.lloyd(dev(Xc, gpu_device), dev(C0, gpu_device), tol_abs=tol)
+    assert n_iter == on
+    assert_labels_match(Xc, oc, labels.cpu().numpy(), ol, allow_near_ties=False)
+    assert np.allclose(centers.cpu().numpy(), oc, rtol=RTOL, atol=1e-6)
+    assert np.isclose(inertia, oi, rtol=RTOL)
+    assert len(np.unique(labels.cpu().numpy())) == k
+    # sklearn's own hand-out order: the same clustering with some of the relocated ids swapped
+    sl, si, _, sn = O.kmeans_single_lloyd(Xc, C0, 300, tol, far_order="argpartition", sums="f64")
+    assert sn == on and np.isclose(si, oi, rtol=1e-6)
+    assert O.is_same_clustering(sl, ol, k) and O.is_same_clustering(ol, sl, k)
+    fl, fi, _, fn = O.kmeans_single_lloyd(Xc, C0, 300, tol, far_order="argpartition")  # sklearn as it is, one thread
+    assert fn == on and np.isclose(fi, oi, rtol=1e-3) and int((fl != sl).sum()) <= n // 100
+    # the batched driver: two such restarts beside an ordinary one
+    C0s = np.stack([C0, Xc[datagen.make_init_indices(93, n, k)], C0[::-1].copy()])
+    lb, ib, cb, nb = K.lloyd_batched(dev(Xc, gpu_device), dev(C0s, gpu_device), tol_abs=tol)
+    assert nb[0] == n_iter and torch.equal(lb[0], labels) and torch.equal(cb[0], centers)
+    for r in (1, 2):
+        l1, i1, c1, n1 = K.lloyd(dev(Xc, gpu_device), dev(C0s[r], gpu_device), tol_abs=tol)
+        assert nb[r] == n1 and torch.equal(lb[r], l1) and torch.equal(cb[r], c1)
+
+
 # ------------------------------------------------------------------------------------------
 # ADE / FDE and best-of-K
 # ------------------------------------------------------------------------------------------
