@@ -16,11 +16,16 @@ The JSON line also carries
   roofline      for the dominant kernel (E-step): algorithmic 2*N*K*D flop / launch over its
                 average duration measured with events on the launch stream, against the fp32
                 matrix peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
-  cpu_baseline  the CPU oracle port (oracle/liboracle.so, OpenMP) timed on a bounded sample of
-                the same workload on this box's host cores (rank 0, N = 1 only);
-and, as extra keys, the M-step kernel's HBM rate, scikit-learn's own KMeans rate when it is
-importable (third-party package, not reference source), and the second half of the metric:
-best-of-K ADE/FDE trajectories/s on configs[4] (1M agents x K=100 x T=12).
+  cpu_baseline  the reference's CPU path -- scikit-learn's KMeans(init=C0, n_init=1), what
+                PCCSNet/utils/utility.py:121 calls -- on a bounded sample of the same workload at the 8
+                threads the reference pins (utility.py:8), with the all-cores figure beside it; the
+                CPU oracle port (oracle/liboracle.so) is the fallback when sklearn is absent and is
+                reported as cpu_baseline_port (rank 0, N = 1 only);
+and, as extra keys, the M-step kernel's HBM rate, the second half of the metric -- best-of-K ADE/FDE
+trajectories/s on configs[4] (1M agents x K=100 x T=12) with the reference's per-agent torch loop and
+NumPy loop as its CPU baselines -- and reference_configs: the whole KMeans(K, n_init=20) fit at the
+reference's own sizes (configs[0..2]: eth N=73 568 / K=200, SDD N=17 970 / K=400) with its dominant
+kernel's roofline.
 """
 import argparse
 import json
@@ -37,6 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, "modular-trajectory-prediction-toolkit_amd
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md, HBM3E peak (spec); ~6300 achievable
+TRAFFIC_SOURCE = "profiles/pmc_traffic.json (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
 
 
 def recorded_traffic(n, d, k, world, eval_cfg=None):
@@ -99,23 +105,129 @@ def cpu_baseline_kmeans(Xs, C0, k, d):
     return out, labels
 
 
-def sklearn_baseline(Xs, C0, k, d):
+def sklearn_baseline(Xs, C0, k, d, threads):
+    """sklearn KMeans(init=C0, n_init=1, max_iter=2) -- the reference's CPU path (PCCSNet/utils/utility.py:121;
+    scikit-learn is its third-party dependency) -- under a thread limit (utility.py:8 pins 8)."""
     try:
         import warnings
         from sklearn.cluster import KMeans
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_limits
     except Exception:  # noqa: BLE001
         return None
-    with warnings.catch_warnings():
+    with warnings.catch_warnings(), threadpool_limits(limits=threads):
         warnings.simplefilter("ignore")
         t0 = time.perf_counter()
         km = KMeans(n_clusters=k, init=C0, n_init=1, max_iter=2, tol=0).fit(Xs)
         dt = time.perf_counter() - t0
-    threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
     # 2 Lloyd iterations + the final E-step = 3 distance passes
-    return {"value": 3 * Xs.shape[0] * k * d / dt, "unit": "distance-evals/s", "threads": threads,
-            "sample": f"sklearn KMeans(init=C0, n_init=1, max_iter=2) on {Xs.shape[0]} points; {dt:.2f} s "
-                      f"({km.n_iter_} iterations + final E-step)"}
+    return {"value": 3 * Xs.shape[0] * k * d / dt, "unit": "distance-evals/s", "cores": threads, "kind": "reference",
+            "sample": f"sklearn KMeans(init=C0, n_init=1, max_iter=2) on the first {Xs.shape[0]} points of the workload, "
+                      f"{threads} threads; {dt:.2f} s ({km.n_iter_} iterations + final E-step = 3 distance passes)"}
+
+
+def host_cores():
+    """This job's share of the host: the GPU box exports OMP_NUM_THREADS = its per-GPU share (16) while
+    os.cpu_count() shows the whole machine."""
+    try:
+        c = len(os.sched_getaffinity(0))
+    except AttributeError:
+        c = os.cpu_count() or 1
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    return min(c, int(env)) if env.isdigit() and int(env) > 0 else c
+
+
+def ms_of(fn, reps=3):
+    """median wall time of fn() in ms, device synchronised on both sides"""
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def reference_config(name, n, k, n_val, seed, device, with_cpu):
+    """BASELINE configs[0..2]: the reference's own call, KMeans(K, n_init=20).fit on [n, 96] encodings, then
+    get_modality and the best-of-20 evaluation, at the reference's sizes (SURVEY.md 8(d) inputs 1-3)."""
+    from pccs_accel import clustering, seeding
+    from pccs_accel import kernels as K
+    d, n_init = 96, 20
+    X = make_encodings(n, d, k, seed=seed, device=device)
+    fit = {}
+
+    def run_fit():
+        np.random.seed(seed)
+        fit["r"] = clustering.kmeans_fit(X, k, n_init=n_init)
+
+    run_fit()  # warm-up (kernel images, allocator)
+    fit_ms = ms_of(run_fit)
+    # the two halves of the fit, separately
+    Xc = X.clone()
+    K.sub_rowvec_(Xc, fit["r"]["x_mean"])
+    rs = np.random.RandomState(seed)
+    draws = [seeding.draw(rs, n, k) for _ in range(n_init)]
+    seeds = {}
+
+    def run_seed():
+        seeds["c"], _ = seeding.kmeans_plusplus_batched(Xc, k, draws)
+
+    run_seed()
+    seed_ms = ms_of(run_seed)
+    lloyd_ms = ms_of(lambda: K.lloyd_batched(Xc, seeds["c"], tol_abs=fit["r"]["tol_abs"], check_every=4))
+    # dominant kernel: the k-means++ candidate-distance GEMM (fp64 on the matrix pipe), timed through the
+    # step-level entry that launches the same kernel on the same shapes (20 restarts x L candidates x n points)
+    l = 2 + int(np.log(k))
+    ops = seeding.DeviceSeedOps()
+    yy = ops.row_sqnorm(Xc)
+    cand = Xc[torch.randint(0, n, (n_init * l,), device=device)].view(n_init, l, d).contiguous()
+    closest = torch.rand((n_init, n), device=device) * 4
+    ops.candidate_dists(Xc, yy, cand, closest)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    e0.record()
+    for _ in range(reps):
+        ops.candidate_dists(Xc, yy, cand, closest)
+    e1.record()
+    torch.cuda.synchronize()
+    step_ms = e0.elapsed_time(e1) / reps
+    flop = 2.0 * n * d * n_init * l   # per launch; the kernel computes whole 8-row tiles: 8 / l times as many
+    # fp64 peak: 78.6 TFLOP/s is AMD's data-sheet figure for MI355X (vector = matrix); MI355X_MICROARCH.md lists no
+    # fp64 row.  Measured on the box (profiles/r01_mfma_f64_rate.txt): v_mfma_f64_16x16x4 47.8, v_fma_f64 69.5.
+    PEAK_F64_MATRIX = 78.6
+    out = {"workload": f"{name}: KMeans(K={k}, n_init={n_init}).fit on N={n} x D={d} synthetic encodings + get_modality "
+                       f"+ best-of-20 ADE/FDE on {n_val} agents",
+           "fit_ms": fit_ms, "seeding_ms": seed_ms, "lloyd_ms": lloyd_ms, "n_iter_best": int(fit["r"]["n_iter"]),
+           "inertia": float(fit["r"]["inertia"]),
+           "roofline": {"bound": "mfma", "kernel": "k_kpp_dist_mfma (+ staging and potential sums of one seeding step)",
+                        "achieved": flop / (step_ms * 1e-3) / 1e12, "peak": PEAK_F64_MATRIX, "unit": "TFLOP/s (fp64)",
+                        "frac": flop / (step_ms * 1e-3) / 1e12 / PEAK_F64_MATRIX, "traffic": None,
+                        "ms_per_launch": step_ms, "algorithmic_flop_per_launch": flop,
+                        "launches_per_fit": k - 1}}
+    labels = fit["r"]["labels"]
+    out["get_modality_ms"] = ms_of(lambda: K.cluster_means(*K.centroid_sums(X, labels, k)))
+    pred, gt = make_trajectories(n_val, 20, 12, seed=seed + 1, device=device)
+    out["best_of_20_ms"] = ms_of(lambda: K.best_of_k(pred, gt, mode=0))
+    if with_cpu:
+        try:
+            import warnings
+            from sklearn.cluster import KMeans
+            from threadpoolctl import threadpool_limits
+            Xh = X.cpu().numpy()
+            with warnings.catch_warnings(), threadpool_limits(limits=8):
+                warnings.simplefilter("ignore")
+                np.random.seed(seed)
+                t0 = time.perf_counter()
+                km = KMeans(n_clusters=k, n_init=2).fit(Xh)
+                cdt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": cdt * 1e3 * n_init / 2, "unit": "ms per fit", "cores": 8, "kind": "reference",
+                                   "sample": f"sklearn KMeans(K, n_init=2) on the same points, 8 threads "
+                                             f"(PCCSNet/utils/utility.py:8): {cdt:.2f} s, scaled to n_init=20",
+                                   "inertia_best_of_2": float(km.inertia_)}
+        except Exception as exc:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(exc)}
+    return out
 
 
 def main():
@@ -132,6 +244,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-ref-configs", action="store_true", help="skip the reference-sized configs (eth, SDD)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo); not a valid scaling result")
@@ -252,11 +365,14 @@ def main():
     achieved_tf = flop / (ms_assign * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": "k_assign_mfma", "achieved": achieved_tf, "peak": PEAK_FP32_MATRIX_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved_tf / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic.get("k_assign_mfma"),
+                "traffic_source": TRAFFIC_SOURCE if traffic.get("k_assign_mfma") is not None else None,
                 "ms_per_launch": ms_assign, "algorithmic_flop_per_launch": flop}
     acc_bytes = n_local * d * 4.0 + n_local * 4.0 + k * d * 8.0 + k * 8.0
     roofline_update = {"bound": "hbm", "kernel": "k_accumulate", "achieved": acc_bytes / (ms_accum * 1e-3) / 1e9,
                        "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": acc_bytes / (ms_accum * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                       "traffic": traffic.get("k_accumulate"), "ms_per_launch": ms_accum, "algorithmic_bytes_per_launch": acc_bytes}
+                       "traffic": traffic.get("k_accumulate"),
+                       "traffic_source": TRAFFIC_SOURCE if traffic.get("k_accumulate") is not None else None,
+                       "ms_per_launch": ms_accum, "algorithmic_bytes_per_launch": acc_bytes}
 
     out = {
         "metric": "k-means iters/sec (N×K×D distance evals/sec) + best-of-K ADE/FDE traj/sec",
@@ -306,24 +422,50 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_best_of_k", "achieved": ebytes / (ms_eval * 1e-3) / 1e9,
                          "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ebytes / (ms_eval * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                          "traffic": traffic.get("k_best_of_k") if (args.eval_n, args.eval_k, args.eval_t) == (1_000_000, 100, 12) else None,
+                         "traffic_source": TRAFFIC_SOURCE if traffic.get("k_best_of_k") is not None else None,
                          "ms_per_launch": ms_eval, "algorithmic_bytes_per_launch": ebytes}}
-        # CPU baseline of this half beside it (rank 0, N = 1 only): the oracle's C restatement of the per-agent
-        # loop (train_steps.py:214-232), a scalar single-thread port, on a bounded sample of the same trajectories
+        # CPU baselines of this half beside it (rank 0, N = 1 only), on bounded samples of the same trajectories:
+        # the reference's per-agent torch loop (PCCSNet/train_steps.py:214-232) and the NumPy loop of
+        # StimulusVerification/verify_predictions.py:238-248 (float64, best of the first 20), both restated in
+        # oracle/glue_oracle.py; the oracle's scalar C port is what the parity gate compares with
         if world == 1 and not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import glue_oracle as G
             import kmeans_oracle as O
+            nt = min(20_000, ehi - elo)
+            pt, gtt = pred[:nt].cpu(), gt[:nt].cpu()
+            torch_threads = torch.get_num_threads()
+            t0 = time.perf_counter()
+            tv = G.evaluate_loop_torch(pt, gtt, mode=0)
+            tdt = time.perf_counter() - t0
+            out["best_of_k"]["cpu_baseline"] = {
+                "value": nt * float(args.eval_k) / tdt, "unit": "traj/s", "cores": torch_threads, "kind": "port",
+                "sample": f"the reference's evaluate loop (train_steps.py:214-232: one agent at a time, torch CPU ops, "
+                          f".item() per agent) on the first {nt} agents, mode 0; {tdt:.2f} s",
+                "mean_ade_fde": [float(tv[0]), float(tv[1])]}
+            nv = min(100_000, ehi - elo)
+            p64, g64 = pred[:nv, :20].cpu().numpy().astype(np.float64), gt[:nv].cpu().numpy().astype(np.float64)
+            t0 = time.perf_counter()
+            G.verify_best_of_numpy(p64, g64, best_of=20)
+            vdt = time.perf_counter() - t0
+            out["best_of_k"]["cpu_baseline_numpy"] = {
+                "value": nv * 20.0 / vdt, "unit": "traj/s", "cores": 1, "kind": "port",
+                "sample": f"verify_predictions.py:238-248 (np.linalg.norm + Python loop over agents, float64) on the first "
+                          f"{nv} agents x best-of-20; {vdt:.2f} s"}
+            del p64, g64
             ns = min(1_000_000, ehi - elo)
             ph, gh = pred[:ns].cpu().numpy(), gt[:ns].cpu().numpy()
             t0 = time.perf_counter()
             o = O.best_of_k(ph, gh, mode=0)
             cdt = time.perf_counter() - t0
             g = K.best_of_k(pred[:ns], gt[:ns], mode=0)
-            out["best_of_k"]["cpu_baseline"] = {
+            out["best_of_k"]["cpu_baseline_port"] = {
                 "value": ns * float(args.eval_k) / cdt, "unit": "traj/s", "cores": 1, "kind": "port",
                 "sample": f"oracle.c best-of-K (scalar, one thread) on the first {ns} agents, mode 0; {cdt:.2f} s"}
             out["best_of_k"]["parity"] = {
                 "sample_agents": int(ns), "argmin_mismatches_vs_cpu_oracle": int((g["idx"].cpu().numpy() != o["idx"]).sum()),
-                "max_rel_err_min_ade": float(np.max(np.abs(g["min_ade"].cpu().numpy() - o["min_ade"]) / np.maximum(o["min_ade"], 1e-30)))}
+                "max_rel_err_min_ade": float(np.max(np.abs(g["min_ade"].cpu().numpy() - o["min_ade"]) / np.maximum(o["min_ade"], 1e-30))),
+                "torch_loop_mean_ade_rel_err": float(abs(tv[0] - float(K.best_of_k(pred[:nt], gt[:nt], mode=0)["sums"][0].item()) / nt) / tv[0])}
         del pred, gt
 
     # ---- CPU baseline on a bounded sample (rank 0, N = 1 only) ----
@@ -331,17 +473,31 @@ def main():
         ns = min(args.cpu_sample, n_local)
         Xs = X[:ns].cpu().numpy()
         C0h = C0.cpu().numpy()
-        base, cpu_labels = cpu_baseline_kmeans(Xs, C0h, k, d)
-        base["iters_per_s_full_n"] = base["value"] / (float(n) * k * d)
-        out["cpu_baseline"] = base
+        port, cpu_labels = cpu_baseline_kmeans(Xs, C0h, k, d)
+        port["iters_per_s_full_n"] = port["value"] / (float(n) * k * d)
         # parity gate run with the benchmark: the GPU E-step on the same sample and centres
         gl = K.assign(X[:ns].contiguous(), C0).cpu().numpy()
         out["parity"] = {"sample_points": int(ns), "label_mismatches_vs_cpu_oracle": int((gl != cpu_labels).sum())}
-        sk = sklearn_baseline(Xs, C0h, k, d)
-        if sk is not None:
-            out["sklearn_baseline"] = sk
+        cores = host_cores()
+        sk8 = sklearn_baseline(Xs, C0h, k, d, min(8, cores))
+        if sk8 is not None:
+            sk8["iters_per_s_full_n"] = sk8["value"] / (float(n) * k * d)
+            out["cpu_baseline"] = sk8
+            if cores > 8:
+                out["cpu_baseline_all_cores"] = sklearn_baseline(Xs, C0h, k, d, cores)
+            out["cpu_baseline_port"] = port
+        else:
+            out["cpu_baseline"] = port
     else:
         out["cpu_baseline"] = None
+
+    # ---- the reference's own sizes: whole n_init=20 fits (rank 0, N = 1 only) ----
+    if world == 1 and not args.no_ref_configs:
+        del X
+        torch.cuda.empty_cache()
+        out["reference_configs"] = {
+            "eth": reference_config("eth split", 73_568, 200, 2_614, 10, device, not args.no_cpu),
+            "sdd": reference_config("SDD", 17_970, 400, 2_829, 20, device, not args.no_cpu)}
 
     if rank == 0:
         print(json.dumps(out))

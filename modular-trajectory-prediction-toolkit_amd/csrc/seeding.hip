@@ -638,57 +638,57 @@ static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const K
 //   sdot:    n1 = n & -32 points: 4 accumulators x 16 lanes over the first n1 & -64 (point 64 s + 16 a + l),
 //            folded 16 -> 8 (l + (l+8)), a last chunk of 32 as 4 x 8, ((a0 + a1) + a2) + a3, the 8-lane fold;
 //            the remaining points one by one in double, rounded to float at the end.
-// k_kpp_pot_blocks: one workgroup per (4096-point block, group of RW rows, restart): the block is staged
-// through LDS with coalesced loads, then one lane per accumulator walks its chain.
+// k_kpp_pot_blocks: one wave per (4096-point block, row, restart): the block is staged through LDS with
+// coalesced loads, then one lane per accumulator walks its chain.
 // ------------------------------------------------------------------------------------------
-static constexpr int KPP_POT_RW = 4;              // rows per workgroup
-static constexpr int KPP_POT_TS = KPP_GB + 8;     // LDS row pitch: the RW x 8 chain lanes hit distinct banks
+// One wave stages one row's block (16 KB of LDS) and walks its chains: every (block, row, restart) is resident
+// at once and the launch lasts one chain -- the kernel is latency-, not bandwidth-bound.
+static constexpr int KPP_POT_TS = KPP_GB;
 
-__global__ __launch_bounds__(256) void k_kpp_pot_blocks(const float *__restrict__ rows0, int64_t n, int n_rows,
-                                                        size_t bstride, float *part0, int64_t nb) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];  // KPP_POT_RW x KPP_POT_TS
+__global__ __launch_bounds__(64) void k_kpp_pot_blocks(const float *__restrict__ rows0, int64_t n, int n_rows,
+                                                       size_t bstride, float *part0, int64_t nb) {
+    __shared__ __attribute__((aligned(16))) float tile[KPP_POT_TS];
     const float *rows = kpp_at(rows0, bstride, blockIdx.z);
     float *part = kpp_at(part0, bstride, blockIdx.z);
     const int tid = threadIdx.x;
     const int64_t m_main = n & ~(int64_t)3;
     const int64_t off = (int64_t)blockIdx.x * KPP_GB;
-    const int nbk = (int)((m_main - off) < KPP_GB ? (m_main - off) : KPP_GB);
-    const int row_base = blockIdx.y * KPP_POT_RW;
-#pragma unroll
-    for (int r = 0; r < KPP_POT_RW; ++r) {
-        const int row = row_base + r;
-        if (row < n_rows) {
-            const float *src = rows + (size_t)row * n + off;
-#pragma unroll 4
-            for (int i = tid; i < nbk; i += 256) tile[r * KPP_POT_TS + i] = src[i];
-        }
+    const int nbk = (int)((m_main - off) < KPP_GB ? (m_main - off) : KPP_GB);  // a multiple of 4
+    const int row = blockIdx.y;
+    const float *src = rows + (size_t)row * n + off;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        float4 *dst4 = reinterpret_cast<float4 *>(tile);
+#pragma unroll 16
+        for (int i = tid; i < nbk / 4; i += 64) dst4[i] = src4[i];
+    } else {
+#pragma unroll 16
+        for (int i = tid; i < nbk; i += 64) tile[i] = src[i];
     }
     __syncthreads();
-    if (tid >= 8 * KPP_POT_RW) return;
-    const int r = tid >> 3, l8 = tid & 7, row = row_base + r;
+    if (tid >= 8) return;
+    const int l8 = tid;
     const int quads = n_rows >> 2;
     const bool pair = (n_rows & 2) && row >= 4 * quads && row < 4 * quads + 2;
-    const float *x = tile + r * KPP_POT_TS;
+    const float *x = tile;
     float acc = 0.f;
-    if (row < n_rows) {
-        if (!pair) {
-            int i = 0;
-            if (nbk & 4) {
-                if (l8 < 4) acc = acc + x[l8];
-                i = 4;
-            }
-#pragma unroll 16
-            for (; i + 8 <= nbk; i += 8) acc = acc + x[i + l8];
-        } else if (l8 < 4) {
-#pragma unroll 16
-            for (int i = 0; i + 4 <= nbk; i += 4) acc = acc + x[i + l8];
+    if (!pair) {
+        int i = 0;
+        if (nbk & 4) {
+            if (l8 < 4) acc = acc + x[l8];
+            i = 4;
         }
+#pragma unroll 32
+        for (; i + 8 <= nbk; i += 8) acc = acc + x[i + l8];
+    } else if (l8 < 4) {
+#pragma unroll 32
+        for (int i = 0; i + 4 <= nbk; i += 4) acc = acc + x[i + l8];
     }
     const float o4 = __shfl_down(acc, 4, 8);
     const float h = pair ? acc : acc + o4;          // lanes 0..3
     const float t = h + __shfl_down(h, 1, 8);       // lanes 0 and 2: h0 + h1, h2 + h3
     const float y = t + __shfl_down(t, 2, 8);       // lane 0
-    if (l8 == 0 && row < n_rows) part[(size_t)row * nb + blockIdx.x] = y;
+    if (l8 == 0) part[(size_t)row * nb + blockIdx.x] = y;
 }
 
 // the first centre's potential (one row per restart) in sdot's order; result -> part[0]
@@ -760,10 +760,7 @@ extern "C" int mtp_blas_order_rowsums_f32(const float *rows, int l, int64_t n, f
     }
     const int64_t nb = kpp_pot_blocks(n);
     if (nb > 0) {
-        constexpr size_t lds = (size_t)KPP_POT_RW * KPP_POT_TS * sizeof(float);
-        MTP_SET_MAX_LDS_ONCE(&k_kpp_pot_blocks, lds);
-        hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)nb, (unsigned)((l + KPP_POT_RW - 1) / KPP_POT_RW), 1), dim3(256),
-                           lds, s, rows, n, l, (size_t)0, part, nb);
+        hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)nb, (unsigned)l, 1), dim3(64), 0, s, rows, n, l, (size_t)0, part, nb);
         MTP_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_kpp_pot_combine, dim3(1), dim3(64), 0, s, rows, n, l, part, nb, out);
@@ -1012,13 +1009,9 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
             } else {
                 pot_nb = kpp_pot_blocks(n);
                 pot_tail = (int)(n & 3);
-                if (pot_nb > 0) {
-                    constexpr size_t lds = (size_t)KPP_POT_RW * KPP_POT_TS * sizeof(float);
-                    MTP_SET_MAX_LDS_ONCE(&k_kpp_pot_blocks, lds);
-                    hipLaunchKernelGGL(k_kpp_pot_blocks,
-                                       dim3((unsigned)pot_nb, (unsigned)((n_prev + KPP_POT_RW - 1) / KPP_POT_RW), (unsigned)batch),
-                                       dim3(256), lds, s, rows_cur, n, n_prev, w.stride, w.pot_part, pot_nb);
-                }
+                if (pot_nb > 0)
+                    hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)pot_nb, (unsigned)n_prev, (unsigned)batch), dim3(64), 0, s,
+                                       rows_cur, n, n_prev, w.stride, w.pot_part, pot_nb);
             }
             MTP_LAUNCH_CHECK();
         }

@@ -153,3 +153,41 @@ def scene_soft_labels(res_class, res_prob, n_cluster):
     for i in range(len(res_class)):
         res[i][res_class[i]] = res_prob[i]
     return res
+
+
+# ---------------------------------------------------------------- CPU baselines of the evaluation loops
+def evaluate_loop_torch(pred, gt, mode=0):
+    """The body of ``evaluate`` (PCCSNet/train_steps.py:214-232, with utils/metrics.py:4-23 inlined) as the
+    reference runs it: one agent at a time (batch_size 1), torch ops on [k, T, 2] tensors, an ``.item()``
+    pair per agent, float64 running sums.  pred [N, k, T, 2], gt [N, T, 2] torch CPU float32 tensors.
+    Returns np.float64[2] = (ADE, FDE) means -- bench.py times this as the best-of-K CPU baseline."""
+    import torch
+    n, k, t, _ = pred.shape
+    val_res = np.zeros(2).astype(float)
+    for i in range(n):
+        net_output, trj_gt = pred[i], gt[i:i + 1]
+        ade = torch.sqrt(((trj_gt - net_output) ** 2).sum(dim=2)).sum(dim=1) / t      # displacement_error(...) / pred_len
+        fde = torch.sqrt(((trj_gt[:, -1] - net_output[:, -1]) ** 2).sum(dim=1))        # final_displacement_error
+        if mode == 0:
+            idx = torch.argmin(ade)
+            val_res += [ade[idx].item(), fde[idx].item()]
+        elif mode == 1:
+            idx = torch.argmin(fde)
+            val_res += [ade[idx].item(), fde[idx].item()]
+        else:
+            val_res += [torch.min(ade).item(), torch.min(fde).item()]
+    return val_res / max(n, 1)
+
+
+def verify_best_of_numpy(preds, fut, best_of=20, fde_prio=False):
+    """StimulusVerification/verify_predictions.py:238-248: one vectorised ``np.linalg.norm`` over the first
+    ``best_of`` stored predictions, then the reference's Python loop over the agents.  preds [N, M, T, 2],
+    fut [N, T, 2] (float64 in the reference).  Returns (ADE, FDE)."""
+    n, _, t, _ = preds.shape
+    diff = np.linalg.norm(preds[:, :best_of] - fut[:, None], axis=-1)
+    tot_ade = tot_fde = 0
+    for i in range(n):
+        idx = np.argmin(diff[i, :, -1]) if fde_prio else np.argmin(np.sum(diff[i], axis=-1))
+        tot_fde += diff[i, idx, -1]
+        tot_ade += np.sum(diff[i, idx])
+    return tot_ade / n / t, tot_fde / n
