@@ -38,6 +38,17 @@ __host__ __device__ __forceinline__ const T *kpp_at(const T *p, size_t stride, i
 static constexpr int KPP_GB = 4096;  // OpenBLAS sgemv_t block length (NBMAX, kernel/x86_64/sgemv_t_4.c)
 __host__ __device__ inline int64_t kpp_pot_blocks(int64_t n) { return ((n & ~(int64_t)3) + KPP_GB - 1) / KPP_GB; }
 
+// Which candidate rows can still hold the smallest float32 potential.  The float32 potential in OpenBLAS order is a
+// chain of at most ~1100 + nb additions of non-negative terms, so it is within (1100 + nb) * 2^-24 relative of the
+// exact sum; a row whose double sum exceeds the smallest double sum by more than twice that (eps, passed in) can
+// neither win nor tie, and its float32 chain need not be walked.  pot64 comes from atomics (its last bits depend
+// on their order), which can only move a row across the eps margin -- where both answers give the same result.
+__device__ __forceinline__ bool kpp_contender(const double *pot64, int n_rows, int row, double eps) {
+    double mn = pot64[0];
+    for (int l = 1; l < n_rows; ++l) mn = pot64[l] < mn ? pot64[l] : mn;
+    return pot64[row] * (1.0 - eps) <= mn * (1.0 + eps);
+}
+
 struct KppWs {
     double *yy;        // [n]  |y|^2 of the upcast rows (shared by all restarts)
     float *rows;       // [2][L][n] closest-distance rows (ping-pong over steps)
@@ -49,6 +60,8 @@ struct KppWs {
     int64_t *cand;     // [L] candidate ids
     int32_t *state;    // [0] = selected candidate of the current rows
     float *pot;        // [1] current potential (float32 like sklearn's)
+    double *pot64;     // [KPP_MAX_L] double sums of the current candidate rows (atomics of the distance kernel): only
+                       // to tell which rows can still be the float32 argmin (kpp_contender)
     float *pot_part;   // [L][nb4k] float32 sums of the rows' 4096-point blocks in OpenBLAS order (MTP_POT_OPENBLAS)
     size_t stride;     // bytes from one restart's block to the next
     size_t bytes;      // total for `batch` restarts
@@ -76,6 +89,7 @@ static KppWs kpp_carve(void *ws, int64_t n, int d, int l, int batch) {
     w.cand = static_cast<int64_t *>(take((size_t)l * 8));
     w.state = static_cast<int32_t *>(take(64));
     w.pot = static_cast<float *>(take(64));
+    w.pot64 = static_cast<double *>(take(KPP_MAX_L * 8));
     w.pot_part = static_cast<float *>(take((size_t)l * kpp_pot_blocks(n) * 4 + 4));
     w.stride = off - first;
     w.bytes = first + w.stride * (size_t)batch;
@@ -110,7 +124,7 @@ __global__ __launch_bounds__(256) void k_kpp_dist(const float *__restrict__ X, i
                                                   const double *__restrict__ cand_xx, const double *__restrict__ yy,
                                                   const float *rows_prev /* [L][n] */, const int32_t *sel_prev,
                                                   int has_prev, float *rows_out /* [L][n] */, double *bsum_out,
-                                                  int64_t nblk, size_t bstride, int ltile) {
+                                                  int64_t nblk, size_t bstride, int ltile, double *pot64) {
     extern __shared__ __attribute__((aligned(16))) double sx[];  // LT * d candidate rows (zero padded)
     __shared__ double part[LT][4];
     {
@@ -121,6 +135,7 @@ __global__ __launch_bounds__(256) void k_kpp_dist(const float *__restrict__ X, i
         sel_prev = kpp_at(sel_prev, bstride, b);
         rows_out = kpp_at(rows_out, bstride, b);
         bsum_out = kpp_at(bsum_out, bstride, b);
+        if (pot64 != nullptr) pot64 = kpp_at(pot64, bstride, b);
     }
     for (int e = threadIdx.x; e < LT * d; e += 256) sx[e] = e < n_cand * d ? cand_x[(size_t)(e % d) * ltile + e / d] : 0.0;
     __syncthreads();
@@ -167,7 +182,9 @@ __global__ __launch_bounds__(256) void k_kpp_dist(const float *__restrict__ X, i
     __syncthreads();
     if (threadIdx.x < n_cand) {
         const int l = threadIdx.x;
-        bsum_out[(size_t)l * nblk + blockIdx.x] = (part[l][0] + part[l][1]) + (part[l][2] + part[l][3]);
+        const double t = (part[l][0] + part[l][1]) + (part[l][2] + part[l][3]);
+        bsum_out[(size_t)l * nblk + blockIdx.x] = t;
+        if (pot64 != nullptr) atomicAdd(pot64 + l, t);
     }
 }
 
@@ -189,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void k_kpp_dist_tile(const float *__restric
                                                        const double *__restrict__ cand_xx0,
                                                        const double *__restrict__ yy, const float *rows_prev0,
                                                        const int32_t *sel_prev0, int has_prev, float *rows_out0,
-                                                       double *bsum_out0, int64_t nblk, size_t bstride, int batch) {
+                                                       double *bsum_out0, int64_t nblk, size_t bstride, int batch,
+                                                       double *pot64_0) {
     constexpr int NC = 16 * CQ;      // candidate columns of the tile (8 per restart)
     constexpr int RB = 2 * CQ;       // restarts per workgroup
     // LDS chunks are double buffered and the next chunk's global loads are issued before this chunk's
@@ -336,7 +354,10 @@ __global__ __launch_bounds__(256, 2) void k_kpp_dist_tile(const float *__restric
         }
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
-        if (use && tx == 0) kpp_at(bsum_out0, bstride, b)[(size_t)l * nblk + blockIdx.x] = sum;
+        if (use && tx == 0) {
+            kpp_at(bsum_out0, bstride, b)[(size_t)l * nblk + blockIdx.x] = sum;
+            if (pot64_0 != nullptr) atomicAdd(kpp_at(pot64_0, bstride, b) + l, sum);
+        }
     }
 }
 
@@ -346,7 +367,7 @@ static void launch_kpp_dist_tile(const float *X, int64_t n, int d, int n_cand, c
                                  hipStream_t s) {
     hipLaunchKernelGGL((k_kpp_dist_tile<CQ>), dim3((unsigned)nblk, (unsigned)((batch + 2 * CQ - 1) / (2 * CQ))), dim3(256),
                        0, s, X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out,
-                       nblk, w.stride, batch);
+                       nblk, w.stride, batch, w.pot64);
 }
 
 
@@ -372,9 +393,9 @@ static constexpr int KPP_MK = 8;   // features per LDS chunk of the MFMA kernel
 // workspace block per restart (all strides equal); mtp_kpp_candidate_dists_f32 runs the kernel on
 // caller-owned arrays with their own pitches.
 struct KppStrides {
-    size_t cand_x, cand_xx, rows_prev, sel, rows_out, bsum;
+    size_t cand_x, cand_xx, rows_prev, sel, rows_out, bsum, pot64;
 };
-__host__ inline KppStrides kpp_uniform_strides(size_t s) { return KppStrides{s, s, s, s, s, s}; }
+__host__ inline KppStrides kpp_uniform_strides(size_t s) { return KppStrides{s, s, s, s, s, s, s}; }
 
 template <int WP, int QB, int MINB = 2>
 __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__restrict__ X, int64_t n, int d, int n_cand,
@@ -383,7 +404,7 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
                                                           const double *__restrict__ yy, const float *rows_prev0,
                                                           const int32_t *sel_prev0, int has_prev, float *rows_out0,
                                                           double *bsum_out0, int64_t nblk, KppStrides st,
-                                                          int batch) {
+                                                          int batch, double *pot64_0) {
     constexpr int WC = 4 / WP;            // waves along the candidate axis
     constexpr int PB = 8 / WP;            // 16-point blocks per wave
     constexpr int NC = WC * QB * 16;      // candidate columns per workgroup
@@ -397,8 +418,18 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: restart indices / pointers stay scalar
     const int j = lane & 15, g = lane >> 4;
     const int wp = wave % WP, wc = wave / WP;
-    const int64_t row0 = (int64_t)blockIdx.x * KPP_TP;
-    const int b0 = blockIdx.y * RB;
+    // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the ncol
+    // workgroups that share a block of points (one per column of restarts) get ids 8 apart: same XCD, back
+    // to back -- the block is fetched from HBM once and the other columns hit in that XCD's L2.  (With the
+    // columns as the grid's second dimension they ran ~nblk dispatches apart and every column streamed X
+    // from memory again.)
+    const int ncol = (batch + RB - 1) / RB;
+    const unsigned slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int64_t bx = (int64_t)(slot / ncol) * 8 + xcd;
+    const int by = slot % ncol;
+    if (bx >= nblk) return;
+    const int64_t row0 = bx * KPP_TP;
+    const int b0 = by * RB;
 
     f64x4 acc[PB][QB];
 #pragma unroll
@@ -551,20 +582,22 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
             double t = part[0][col];
 #pragma unroll
             for (int w = 1; w < WP; ++w) t += part[w][col];
-            kpp_at(bsum_out0, st.bsum, b)[(size_t)l * nblk + blockIdx.x] = t;
+            kpp_at(bsum_out0, st.bsum, b)[(size_t)l * nblk + bx] = t;
+            if (pot64_0 != nullptr) atomicAdd(kpp_at(pot64_0, st.pot64, b) + l, t);
         }
     }
 }
 
 template <int WP, int QB, int MINB = 2>
-static void launch_kpp_dist_mfma(const float *X, int64_t n, int d, int n_cand, const double *cand_x, const double *cand_xx,
-                                 const double *yy, const float *rows_prev, const int32_t *sel_prev, int has_prev,
-                                 float *rows_out, double *bsum_out, int64_t nblk, KppStrides st, int batch,
-                                 hipStream_t s) {
+static void launch_kpp_dist_mfma(const float *X, int64_t n, int d, int n_cand, const double *cand_x,
+                                 const double *cand_xx, const double *yy, const float *rows_prev, const int32_t *sel_prev,
+                                 int has_prev, float *rows_out, double *bsum_out, int64_t nblk, KppStrides st, int batch,
+                                 double *pot64, hipStream_t s) {
     constexpr int RB = (4 / WP) * QB * 2;
-    hipLaunchKernelGGL((k_kpp_dist_mfma<WP, QB, MINB>), dim3((unsigned)nblk, (unsigned)((batch + RB - 1) / RB)), dim3(256), 0, s,
-                       X, n, d, n_cand, cand_x, cand_xx, yy, rows_prev, sel_prev, has_prev, rows_out, bsum_out, nblk, st,
-                       batch);
+    const int64_t ncol = (batch + RB - 1) / RB;
+    const dim3 grid((unsigned)(((nblk + 7) / 8) * 8 * ncol));  // 1-D, XCD-aware (see the kernel)
+    hipLaunchKernelGGL((k_kpp_dist_mfma<WP, QB, MINB>), grid, dim3(256), 0, s, X, n, d, n_cand, cand_x, cand_xx, yy, rows_prev,
+                       sel_prev, has_prev, rows_out, bsum_out, nblk, st, batch, pot64);
 }
 
 // 4 restarts (32 candidate rows) per workgroup column: 80 VGPRs, 6 workgroups per CU, so the grid
@@ -573,13 +606,13 @@ static void launch_kpp_dist_mfma(const float *X, int64_t n, int d, int n_cand, c
 static void launch_kpp_dist_mfma_any(const float *X, int64_t n, int d, int n_cand, const double *cand_x,
                                      const double *cand_xx, const double *yy, const float *rows_prev,
                                      const int32_t *sel_prev, int has_prev, float *rows_out, double *bsum_out,
-                                     int64_t nblk, KppStrides st, int batch, hipStream_t s) {
+                                     int64_t nblk, KppStrides st, int batch, double *pot64, hipStream_t s) {
     if (batch > 2)
         launch_kpp_dist_mfma<4, 2, 6>(X, n, d, n_cand, cand_x, cand_xx, yy, rows_prev, sel_prev, has_prev, rows_out, bsum_out,
-                                      nblk, st, batch, s);
+                                      nblk, st, batch, pot64, s);
     else
         launch_kpp_dist_mfma<4, 1, 6>(X, n, d, n_cand, cand_x, cand_xx, yy, rows_prev, sel_prev, has_prev, rows_out, bsum_out,
-                                      nblk, st, batch, s);
+                                      nblk, st, batch, pot64, s);
 }
 
 __host__ inline bool kpp_tile_path(int d, int l) { return d % KPP_KC == 0 && l <= 8; }
@@ -593,7 +626,7 @@ static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const K
         const char *sel = getenv("MTP_KPP_KERNEL");
         if (sel == nullptr || strcmp(sel, "fma") != 0) {
             launch_kpp_dist_mfma_any(X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy, rows_prev, w.state, has_prev, rows_out,
-                                     bsum_out, nblk, kpp_uniform_strides(w.stride), batch, s);
+                                     bsum_out, nblk, kpp_uniform_strides(w.stride), batch, w.pot64, s);
             MTP_LAUNCH_CHECK();
             return MTP_OK;
         }
@@ -609,13 +642,13 @@ static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const K
     }
     if (n_cand == 1)
         hipLaunchKernelGGL(k_kpp_dist<1>, grid, block, (size_t)1 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy,
-                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride, ltile);
+                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride, ltile, w.pot64);
     else if (n_cand <= 8)
         hipLaunchKernelGGL(k_kpp_dist<8>, grid, block, (size_t)8 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx, w.yy,
-                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride, ltile);
+                           rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride, ltile, w.pot64);
     else
         hipLaunchKernelGGL(k_kpp_dist<16>, grid, block, (size_t)16 * d * 8, s, X, n, d, n_cand, w.cand_x, w.cand_xx,
-                           w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride, ltile);
+                           w.yy, rows_prev, w.state, has_prev, rows_out, bsum_out, nblk, w.stride, ltile, w.pot64);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
@@ -646,7 +679,8 @@ static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const K
 static constexpr int KPP_POT_TS = KPP_GB;
 
 __global__ __launch_bounds__(64) void k_kpp_pot_blocks(const float *__restrict__ rows0, int64_t n, int n_rows,
-                                                       size_t bstride, float *part0, int64_t nb) {
+                                                       size_t bstride, float *part0, int64_t nb,
+                                                       const double *pot64_0, double eps) {
     __shared__ __attribute__((aligned(16))) float tile[KPP_POT_TS];
     const float *rows = kpp_at(rows0, bstride, blockIdx.z);
     float *part = kpp_at(part0, bstride, blockIdx.z);
@@ -655,6 +689,8 @@ __global__ __launch_bounds__(64) void k_kpp_pot_blocks(const float *__restrict__
     const int64_t off = (int64_t)blockIdx.x * KPP_GB;
     const int nbk = (int)((m_main - off) < KPP_GB ? (m_main - off) : KPP_GB);  // a multiple of 4
     const int row = blockIdx.y;
+    // rows that cannot hold the smallest potential are skipped (k_kpp_select applies the same test)
+    if (pot64_0 != nullptr && !kpp_contender(kpp_at(pot64_0, bstride, blockIdx.z), n_rows, row, eps)) return;
     const float *src = rows + (size_t)row * n + off;
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const float4 *src4 = reinterpret_cast<const float4 *>(src);
@@ -760,7 +796,8 @@ extern "C" int mtp_blas_order_rowsums_f32(const float *rows, int l, int64_t n, f
     }
     const int64_t nb = kpp_pot_blocks(n);
     if (nb > 0) {
-        hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)nb, (unsigned)l, 1), dim3(64), 0, s, rows, n, l, (size_t)0, part, nb);
+        hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)nb, (unsigned)l, 1), dim3(64), 0, s, rows, n, l, (size_t)0, part, nb,
+                           (const double *)nullptr, 0.0);
         MTP_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_kpp_pot_combine, dim3(1), dim3(64), 0, s, rows, n, l, part, nb, out);
@@ -780,10 +817,11 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
                                                      size_t bstride, size_t u_stride /* doubles */,
                                                      size_t index_stride /* int64s */, int ltile,
                                                      const float *pot_part /* NULL: double sums */, int64_t pot_nb,
-                                                     int pot_tail) {
+                                                     int pot_tail, double *pot64, double pot_eps) {
     {
         const int b = blockIdx.x;
         if (pot_part != nullptr) pot_part = kpp_at(pot_part, bstride, b);
+        pot64 = kpp_at(pot64, bstride, b);
         if (u != nullptr) u += u_stride * b;
         rows_cur = kpp_at(rows_cur, bstride, b);
         bsum_cur = kpp_at(bsum_cur, bstride, b);
@@ -820,16 +858,21 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
             pots[tid] = (float)t;
         }
     } else if (tid < n_prev) {
-        // OpenBLAS order (see k_kpp_pot_blocks): y += block sum, block by block, then the n & 3 trailing points
-        float y = 0.f;
-        for (int64_t b = 0; b < pot_nb; ++b) y = y + pot_part[(size_t)tid * pot_nb + b];
-        const float *tail = rows_cur + (size_t)tid * n + (n - pot_tail);
-        if (pot_tail == 3) y = y + ((tail[0] + tail[1]) + tail[2]);
-        else if (pot_tail == 2) y = y + (tail[0] + tail[1]);
-        else if (pot_tail == 1) y = y + tail[0];
+        // OpenBLAS order (see k_kpp_pot_blocks): y += block sum, block by block, then the n & 3 trailing points;
+        // rows that cannot hold the smallest potential were not summed and are out of the argmin
+        float y = __builtin_inff();
+        if (n_prev == 1 || kpp_contender(pot64, n_prev, tid, pot_eps)) {
+            y = 0.f;
+            for (int64_t b = 0; b < pot_nb; ++b) y = y + pot_part[(size_t)tid * pot_nb + b];
+            const float *tail = rows_cur + (size_t)tid * n + (n - pot_tail);
+            if (pot_tail == 3) y = y + ((tail[0] + tail[1]) + tail[2]);
+            else if (pot_tail == 2) y = y + (tail[0] + tail[1]);
+            else if (pot_tail == 1) y = y + tail[0];
+        }
         pots[tid] = y;
     }
     __syncthreads();
+    if (tid < KPP_MAX_L) pot64[tid] = 0.0;  // the next distance kernel adds its rows' block sums here
     if (tid == 0) {
         int best = 0;
         for (int l = 1; l < n_prev; ++l)
@@ -988,11 +1031,13 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
     hipLaunchKernelGGL(k_kpp_first, dim3(batch), dim3(64), 0, s, X, d, center_id, center_ids_dev, w.cand, w.cand_x,
                        w.cand_xx, w.stride, ltile);
     MTP_LAUNCH_CHECK();
+    MTP_HIP(hipMemset2DAsync(w.pot64, w.stride, 0, KPP_MAX_L * 8, batch, s));
     // closest distances to the first centre: one "candidate", no previous row
     int rc = launch_kpp_dist(X, n, d, 1, w, nullptr, 0, w.rows, w.bsum, nblk, batch, ltile, s);
     if (rc != MTP_OK) return rc;
     int cur = 0, n_prev = 1;
     const size_t u_stride = (size_t)(k - 1) * l;
+    const double pot_eps = (1100.0 + (double)kpp_pot_blocks(n)) * (1.0 / 8388608.0);  // see kpp_contender
     for (int c = 1; c <= k; ++c) {
         // select among the previous candidates -> centre c-1; draw the candidates for centre c
         const int n_new = c < k ? l : 0;
@@ -1011,7 +1056,7 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
                 pot_tail = (int)(n & 3);
                 if (pot_nb > 0)
                     hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)pot_nb, (unsigned)n_prev, (unsigned)batch), dim3(64), 0, s,
-                                       rows_cur, n, n_prev, w.stride, w.pot_part, pot_nb);
+                                       rows_cur, n, n_prev, w.stride, w.pot_part, pot_nb, w.pot64, pot_eps);
             }
             MTP_LAUNCH_CHECK();
         }
@@ -1019,12 +1064,12 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
             hipLaunchKernelGGL(k_kpp_select<KPP_TP / 64>, dim3(batch), dim3(1024), 0, s, X, n, d, n_prev, n_new,
                                c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
                                w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1), w.stride, u_stride, (size_t)k,
-                               ltile, pot_part, pot_nb, pot_tail);
+                               ltile, pot_part, pot_nb, pot_tail, w.pot64, pot_eps);
         else
             hipLaunchKernelGGL(k_kpp_select<KPP_PB / 64>, dim3(batch), dim3(1024), 0, s, X, n, d, n_prev, n_new,
                                c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
                                w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1), w.stride, u_stride, (size_t)k,
-                               ltile, pot_part, pot_nb, pot_tail);
+                               ltile, pot_part, pot_nb, pot_tail, w.pot64, pot_eps);
         MTP_LAUNCH_CHECK();
         if (c == k) break;
         float *rows_nxt = w.rows + (size_t)(cur ^ 1) * l * n;
@@ -1169,8 +1214,9 @@ extern "C" int mtp_kpp_candidate_dists_f32(const float *X, int64_t n, int d, con
     st.sel = 0;
     st.rows_out = (size_t)n_cand * n * sizeof(float);
     st.bsum = (size_t)8 * nblk * sizeof(double);
+    st.pot64 = 0;
     launch_kpp_dist_mfma_any(X, n, d, n_cand, w.cand_x, w.cand_xx, yy, closest, w.zero, closest != nullptr ? 1 : 0, rows_out,
-                             w.bsum, nblk, st, batch, s);
+                             w.bsum, nblk, st, batch, nullptr, s);
     MTP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_kpp_potentials, dim3(batch), dim3(1024), 0, s, w.bsum, nblk, n_cand, pot_out);
     MTP_LAUNCH_CHECK();

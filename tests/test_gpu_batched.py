@@ -34,7 +34,7 @@ def test_batched_seeding_equals_single(n, d, k, b, gpu_device):
 @pytest.mark.parametrize("n,d,k,b", [(3001, 96, 40, 1), (2500, 128, 25, 3), (4099, 64, 30, 6), (3333, 96, 64, 20),
                                      (1500, 96, 16, 23)])
 def test_seeding_mfma_kernel_equals_fma_chain_kernel(n, d, k, b, gpu_device, monkeypatch):
-    """The fp64-MFMA distance kernel (every instantiation: 1-2, 3-4, 5-8, 9+ restarts per workgroup column,
+    """The scalar-operand vector kernel (the default) and the fp64-MFMA distance kernel (every instantiation: 1-2, 3-4, 5-8, 9+ restarts per workgroup column,
     and more restarts than one column holds) against the multiply-add chain kernel it replaces: same
     seeds, same centres.  (tools/mfma_f64_order checks the instruction's accumulation order itself.)"""
     from pccs_accel import seeding
@@ -45,9 +45,13 @@ def test_seeding_mfma_kernel_equals_fma_chain_kernel(n, d, k, b, gpu_device, mon
     monkeypatch.setenv("MTP_KPP_KERNEL", "fma")
     c_fma, i_fma = seeding.kmeans_plusplus_batched(Xc, k, draws)
     torch.cuda.synchronize()
-    monkeypatch.delenv("MTP_KPP_KERNEL")
+    monkeypatch.setenv("MTP_KPP_KERNEL", "mfma")
     c_mfma, i_mfma = seeding.kmeans_plusplus_batched(Xc, k, draws)
+    torch.cuda.synchronize()
     assert torch.equal(i_fma, i_mfma) and torch.equal(c_fma, c_mfma)
+    monkeypatch.delenv("MTP_KPP_KERNEL")  # the default: the scalar-operand vector kernel (k_kpp_dist_valu)
+    c_valu, i_valu = seeding.kmeans_plusplus_batched(Xc, k, draws)
+    assert torch.equal(i_fma, i_valu) and torch.equal(c_fma, c_valu)
     # and against the CPU oracle's replay of sklearn, restart 0
     oc, oi = O.kmeans_plusplus(np.ascontiguousarray(Xc.cpu().numpy()), k, np.random.RandomState(4))
     assert np.array_equal(i_mfma[0].cpu().numpy(), oi)
