@@ -32,6 +32,7 @@ extern "C" {
 #define MTP_E_ARG (-1)      /* bad argument (shape, alignment, null pointer) */
 #define MTP_E_HIP (-2)      /* a HIP runtime call failed */
 #define MTP_E_WORKSPACE (-3) /* workspace too small */
+#define MTP_E_COMM (-4)      /* an RCCL call failed, or librccl.so is not available */
 
 /* Lloyd loop states (flags[MTP_FLAG_STATE]) */
 #define MTP_STATE_RUNNING 0
@@ -179,6 +180,36 @@ int mtp_apply_relocation_f32(double *red, int k, int d, int m, const float *far_
 int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int max_iter, double tol_abs,
                   int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, void *ws,
                   size_t ws_bytes, void *stream);
+
+/* ---- the same run with the points sharded over the GPUs of a node: one process per GPU, RCCL over xGMI ----
+ *   The reference has no distributed code; this is the multi-GPU form of the entry above.
+ * A communicator is RCCL's: rank 0 calls mtp_comm_unique_id (128 bytes), the bytes reach every rank by any
+ * channel (torch.distributed, MPI, a file), and every rank calls mtp_comm_create -- a collective -- with its own
+ * GPU current.  librccl.so is bound at run time from the process (the one PyTorch-ROCm loaded) or the system.
+ * mtp_lloyd_sharded_f32: rank r holds rows [row_offset, row_offset + n_local) of the n_total centred points and the
+ * same initial centres; per iteration the library issues ONE ncclAllReduce(sum) of the packed double buffer
+ * [k*d sums | k counts | n_changed | spare] on `stream` between the local sums and the M-step finish, so the
+ * loop runs without the host between checks; empty clusters: ncclAllGather of the ranks' local far points.
+ *   labels_out [n_local] this rank's labels; C_inout: final centres, identical on every rank;
+ *   inertia_out: 1 double (device), the global inertia; n_iter_out: HOST int;
+ *   phase_ms_out: NULL, or 3 HOST floats = average milliseconds of (E-step, local sums, all-reduce + M-step finish)
+ *     per iteration, from HIP events the library records on `stream`;
+ *   options: 0, or MTP_LLOYD_NO_FINAL_ESTEP: when the loop ends on max_iter / the tolerance the closing E-step
+ *     (sklearn _kmeans.py:736-748) is left out and labels_out are those of the last iteration -- for callers
+ *     that time a fixed number of iterations (bench.py) or run the closing step themselves;
+ *   ws: mtp_lloyd_sharded_workspace_bytes(k, d, n_local, world) bytes.
+ * Every rank must call with the same k, d, max_iter, tol_abs, check_every.  comm == NULL: one rank holding all
+ * points (mtp_lloyd_f32 with the timing / options arguments). */
+#define MTP_LLOYD_NO_FINAL_ESTEP 1
+typedef struct mtp_comm mtp_comm;
+int mtp_comm_unique_id(void *id_out);
+int mtp_comm_create(int rank, int world, const void *id, mtp_comm **out);
+int mtp_comm_destroy(mtp_comm *comm);
+int64_t mtp_lloyd_sharded_workspace_bytes(int k, int d, int64_t n_local, int world);
+int mtp_lloyd_sharded_f32(const mtp_comm *comm, const float *X_local, int64_t n_local, int64_t row_offset, int64_t n_total,
+                          int d, float *C_inout, int k, int max_iter, double tol_abs, int check_every, int32_t *labels_out,
+                          double *inertia_out, int *n_iter_out, float *phase_ms_out, int options, void *ws, size_t ws_bytes,
+                          void *stream);
 
 /* n_init restarts at once (the loop over inits of sklearn KMeans.fit, cluster/_kmeans.py:1495-1532, which
  * PCCSNet/utils/utility.py:120-121 runs with n_init=20): `batch` independent mtp_lloyd_f32 runs on the same

@@ -1,4 +1,6 @@
 // C-ABI entry points of libmtp_accel.so (see include/mtp_accel.h) and the single-GPU Lloyd driver.
+#include <dlfcn.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -196,26 +198,252 @@ extern "C" int mtp_lloyd_mstep_f32(double *red, const float *C_old, float *C_new
                             red_backup, mtp_stream(stream));
 }
 
+// ---- RCCL, bound at run time ----
+// The library does not link librccl: it looks the five entry points up in the librccl.so the process already
+// holds (PyTorch-ROCm ships one and loads it with torch; a second copy in the process would mean a second set of
+// device state), else in the system's.  A box without RCCL can still use everything that is not sharded.
+typedef struct ncclComm *mtp_nccl_comm_t;
+struct MtpNcclId {
+    char internal[128];  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
+};
+namespace {
+struct Rccl {
+    int (*GetUniqueId)(MtpNcclId *) = nullptr;
+    int (*CommInitRank)(mtp_nccl_comm_t *, int, MtpNcclId, int) = nullptr;
+    int (*CommDestroy)(mtp_nccl_comm_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, mtp_nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, mtp_nccl_comm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+constexpr int kNcclSum = 0, kNcclChar = 0, kNcclDouble = 8;  // rccl.h: ncclSum, ncclChar, ncclFloat64
+
+const Rccl &rccl() {
+    static Rccl r = [] {
+        Rccl q;
+        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (h == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (h == nullptr) return q;
+        q.GetUniqueId = reinterpret_cast<decltype(q.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        q.CommInitRank = reinterpret_cast<decltype(q.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        q.CommDestroy = reinterpret_cast<decltype(q.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        q.AllReduce = reinterpret_cast<decltype(q.AllReduce)>(dlsym(h, "ncclAllReduce"));
+        q.AllGather = reinterpret_cast<decltype(q.AllGather)>(dlsym(h, "ncclAllGather"));
+        q.GetErrorString = reinterpret_cast<decltype(q.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        q.ok = q.GetUniqueId && q.CommInitRank && q.CommDestroy && q.AllReduce && q.AllGather && q.GetErrorString;
+        return q;
+    }();
+    return r;
+}
+}  // namespace
+
+#define MTP_NCCL(expr)                                                                                        \
+    do {                                                                                                      \
+        const int e_ = (expr);                                                                                \
+        if (e_ != 0) {                                                                                        \
+            mtp_set_error("%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(e_), __FILE__, __LINE__);     \
+            return MTP_E_COMM;                                                                                \
+        }                                                                                                     \
+    } while (0)
+
+struct mtp_comm {
+    mtp_nccl_comm_t nccl;
+    int rank, world, device;
+};
+
+extern "C" int mtp_comm_unique_id(void *id_out) {
+    MTP_REQUIRE(id_out != nullptr, "mtp_comm_unique_id: null pointer");
+    if (!rccl().ok) {
+        mtp_set_error("mtp_comm_unique_id: librccl.so not found in this process or on the library path");
+        return MTP_E_COMM;
+    }
+    MTP_NCCL(rccl().GetUniqueId(static_cast<MtpNcclId *>(id_out)));
+    return MTP_OK;
+}
+
+extern "C" int mtp_comm_create(int rank, int world, const void *id, mtp_comm **out) {
+    MTP_REQUIRE(id != nullptr && out != nullptr && world >= 1 && rank >= 0 && rank < world, "mtp_comm_create: bad arguments");
+    if (!rccl().ok) {
+        mtp_set_error("mtp_comm_create: librccl.so not found in this process or on the library path");
+        return MTP_E_COMM;
+    }
+    MtpNcclId uid;
+    memcpy(&uid, id, sizeof(uid));
+    mtp_comm *c = new mtp_comm{nullptr, rank, world, 0};
+    hipError_t he = hipGetDevice(&c->device);
+    if (he != hipSuccess) {
+        delete c;
+        mtp_set_error("mtp_comm_create: hipGetDevice failed: %s", hipGetErrorString(he));
+        return MTP_E_HIP;
+    }
+    const int e = rccl().CommInitRank(&c->nccl, world, uid, rank);  // collective: every rank calls it, on its own GPU
+    if (e != 0) {
+        mtp_set_error("mtp_comm_create: ncclCommInitRank failed: %s", rccl().GetErrorString(e));
+        delete c;
+        return MTP_E_COMM;
+    }
+    *out = c;
+    return MTP_OK;
+}
+
+extern "C" int mtp_comm_destroy(mtp_comm *c) {
+    if (c == nullptr) return MTP_OK;
+    const int e = rccl().CommDestroy(c->nccl);
+    delete c;
+    if (e != 0) {
+        mtp_set_error("mtp_comm_destroy: ncclCommDestroy failed: %s", rccl().GetErrorString(e));
+        return MTP_E_COMM;
+    }
+    return MTP_OK;
+}
+
+// Global top-m of the ranks' local far points (all-gathered, W * m entries): descending distance, ties to the
+// lowest global row index, entries without a point (index < 0) last -- what one GPU's search over all points
+// would return.  One block; rank by counting (the lists are short, and empty clusters are rare).
+__global__ __launch_bounds__(1024) void k_far_merge(const float *gval, const int64_t *gidx, const int32_t *glab,
+                                                    const float *grows, int total, int m, int d, float *val,
+                                                    int64_t *idx, int32_t *lab, float *rows) {
+    for (int q = threadIdx.x; q < m; q += blockDim.x) {  // "no candidate" unless a ranked entry lands here
+        val[q] = -1.f;
+        idx[q] = -1;
+        lab[q] = -1;
+    }
+    for (int e = threadIdx.x; e < m * d; e += blockDim.x) rows[e] = 0.f;
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int64_t ie = gidx[e];
+        if (ie < 0) continue;
+        const float ve = gval[e];
+        int rank = 0;
+        for (int j = 0; j < total; ++j) {
+            const int64_t ij = gidx[j];
+            if (ij >= 0 && (gval[j] > ve || (gval[j] == ve && ij < ie))) ++rank;
+        }
+        if (rank < m) {
+            val[rank] = ve;
+            idx[rank] = ie;
+            lab[rank] = glab[e];
+            for (int c = 0; c < d; ++c) rows[(size_t)rank * d + c] = grows[(size_t)e * d + c];
+        }
+    }
+}
+
+__global__ void k_fill_no_far_points(float *val, int64_t *idx, int32_t *lab, float *rows, int m, int d) {
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < m * d; q += gridDim.x * blockDim.x) {
+        rows[q] = 0.f;
+        if (q < m) {
+            val[q] = -1.f;
+            idx[q] = -1;
+            lab[q] = -1;
+        }
+    }
+}
+
 // ---- whole single-GPU run: sklearn _kmeans_single_lloyd (cluster/_kmeans.py:624-752) ----
-extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int max_iter, double tol_abs,
-                             int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, void *ws,
-                             size_t ws_bytes, void *stream) {
-    MTP_REQUIRE(X && C_inout && labels_out && ws, "mtp_lloyd: null pointer");
-    MTP_REQUIRE(n >= k && k >= 1 && d >= 1 && max_iter >= 1, "mtp_lloyd: bad shape n=%lld k=%d d=%d max_iter=%d",
-                (long long)n, k, d, max_iter);
+// Points sharded over the ranks of `cm` (NULL: one GPU): every rank runs the same loop on its rows; per
+// iteration ONE all-reduce (sum) of the packed double buffer red = [k*d sums | k counts | n_changed | spare],
+// after which every rank finishes the M-step identically -- centres, norms and loop state stay replicated bit
+// for bit, no broadcast.  Empty clusters: the ranks' local top-m far points are all-gathered and merged
+// (k_far_merge).  Iterations enqueued behind a pause are no-ops, but their all-reduces are not: the paused
+// M-step parks red in red_backup and zeroes it, so those all-reduces add zeros (mtp_lloyd_mstep_f32).
+struct ShardWs {
+    double *red_backup;
+    float *g_val;
+    int64_t *g_idx;
+    int32_t *g_lab;
+    float *g_rows;
+    double *inertia;
+    size_t bytes;
+};
+static ShardWs carve_shard(void *ws, int k, int d, int world) {
+    ShardWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *p = ws ? static_cast<char *>(ws) + off : nullptr;
+        off += align_up(bytes, 256);
+        return p;
+    };
+    w.red_backup = static_cast<double *>(take((size_t)mtp_red_len(k, d) * 8));
+    w.g_val = static_cast<float *>(take((size_t)world * k * 4));
+    w.g_idx = static_cast<int64_t *>(take((size_t)world * k * 8));
+    w.g_lab = static_cast<int32_t *>(take((size_t)world * k * 4));
+    w.g_rows = static_cast<float *>(take((size_t)world * k * d * 4));
+    w.inertia = static_cast<double *>(take(8));
+    w.bytes = off;
+    return w;
+}
+
+extern "C" int64_t mtp_lloyd_sharded_workspace_bytes(int k, int d, int64_t n_local, int world) {
+    if (k <= 0 || d <= 0 || n_local < 0 || world <= 0) return 0;
+    return (int64_t)(carve_lloyd(nullptr, k, d).bytes + (size_t)mtp_far_points_scratch_bytes(n_local) +
+                     carve_shard(nullptr, k, d, world).bytes);
+}
+
+static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_offset, int d, float *C_inout, int k,
+                     int max_iter, double tol_abs, int check_every, int32_t *labels_out, double *inertia_out,
+                     int *n_iter_out, float *phase_ms_out, int options, void *ws, size_t ws_bytes, void *stream) {
     LloydWs w = carve_lloyd(ws, k, d);
-    const size_t need = w.bytes + (size_t)mtp_far_points_scratch_bytes(n);
+    const size_t scratch_bytes = (size_t)mtp_far_points_scratch_bytes(n);
+    float *dist_scratch = reinterpret_cast<float *>(static_cast<char *>(ws) + w.bytes);
+    ShardWs sw{};
+    size_t need = w.bytes + scratch_bytes;
+    if (cm != nullptr) {
+        sw = carve_shard(static_cast<char *>(ws) + need, k, d, cm->world);
+        need += sw.bytes;
+    }
     if (ws_bytes < need) {
         mtp_set_error("mtp_lloyd: workspace of %zu bytes, need %zu", ws_bytes, need);
         return MTP_E_WORKSPACE;
     }
-    float *dist_scratch = reinterpret_cast<float *>(static_cast<char *>(ws) + w.bytes);
     hipStream_t s = mtp_stream(stream);
     if (check_every < 1) check_every = 1;
+    const int64_t red_len = mtp_red_len(k, d);
 
     int rc = mtp_lloyd_begin_f32(C_inout, k, d, w.staged, w.c2, w.red, w.flags, stream);
     if (rc != MTP_OK) return rc;
-    MTP_HIP(hipMemsetAsync(labels_out, 0xff, (size_t)n * 4, s));  // labels_old = -1 (_kmeans.py:685)
+    if (n > 0) MTP_HIP(hipMemsetAsync(labels_out, 0xff, (size_t)n * 4, s));  // labels_old = -1 (_kmeans.py:685)
+
+    // optional per-phase timing (bench.py): events around the E-step / the sums / all-reduce + M-step finish
+    std::vector<hipEvent_t> ev;
+    auto mark = [&]() -> int {
+        if (phase_ms_out == nullptr) return MTP_OK;
+        hipEvent_t e;
+        MTP_HIP(hipEventCreate(&e));
+        ev.push_back(e);
+        MTP_HIP(hipEventRecord(e, s));
+        return MTP_OK;
+    };
+    struct EvGuard {
+        std::vector<hipEvent_t> &v;
+        ~EvGuard() {
+            for (hipEvent_t e : v) (void)hipEventDestroy(e);
+        }
+    } ev_guard{ev};
+
+    // one iteration: E-step, local sums, [all-reduce], M-step finish (pauses on an empty cluster)
+    auto iteration = [&](const float *c_old, float *c_new) -> int {
+        int r = mark();
+        if (r != MTP_OK) return r;
+        if (n > 0) {
+            r = mtp_lloyd_assign_f32(X, n, d, c_old, w.staged, w.c2, k, labels_out, w.red, w.flags, stream);
+            if (r != MTP_OK) return r;
+        }
+        r = mark();
+        if (r != MTP_OK) return r;
+        if (n > 0) {
+            r = mtp_lloyd_accumulate_f32(X, n, d, labels_out, k, w.red, w.flags, stream);
+            if (r != MTP_OK) return r;
+        }
+        r = mark();
+        if (r != MTP_OK) return r;
+        if (cm != nullptr) MTP_NCCL(rccl().AllReduce(w.red, w.red, (size_t)red_len, kNcclDouble, kNcclSum, cm->nccl, s));
+        r = mtp_launch_mstep(w.red, c_old, c_new, k, d, tol_abs, max_iter, 0, w.staged, w.c2, w.shift, w.flags,
+                             cm != nullptr ? sw.red_backup : nullptr, s);
+        if (r != MTP_OK) return r;
+        return mark();
+    };
 
     // centres ping-pong between C_inout (cur = 0) and the workspace copy (cur = 1)
     float *cbuf[2] = {C_inout, w.c_alt};
@@ -225,10 +453,7 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
     for (;;) {
         const int budget = (max_iter - enq_iters) < check_every ? (max_iter - enq_iters) : check_every;
         for (int i = 0; i < budget; ++i) {
-            rc = mtp_lloyd_estep_f32(X, n, d, cbuf[cur], w.staged, w.c2, k, labels_out, w.red, w.flags, stream);
-            if (rc != MTP_OK) return rc;
-            rc = mtp_launch_mstep(w.red, cbuf[cur], cbuf[cur ^ 1], k, d, tol_abs, max_iter, 0, w.staged, w.c2, w.shift,
-                                  w.flags, nullptr, s);
+            rc = iteration(cbuf[cur], cbuf[cur ^ 1]);
             if (rc != MTP_OK) return rc;
             cur ^= 1;
             ++enq_iters;
@@ -241,9 +466,25 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
             // red are valid.  The centres it read are in parity (done_iters & 1).
             const int old = done_iters & 1;
             const int m = hflags[MTP_FLAG_N_EMPTY];  // < k: at least one cluster holds points
-            rc = mtp_far_points_f32(X, n, d, cbuf[old], labels_out, m, 0, w.far_val, w.far_idx, w.far_lab, w.far_rows,
-                                    dist_scratch, stream);
-            if (rc != MTP_OK) return rc;
+            if (n > 0) {
+                rc = mtp_far_points_f32(X, n, d, cbuf[old], labels_out, m, row_offset, w.far_val, w.far_idx, w.far_lab,
+                                        w.far_rows, dist_scratch, stream);
+                if (rc != MTP_OK) return rc;
+            } else {
+                hipLaunchKernelGGL(k_fill_no_far_points, dim3(64), dim3(256), 0, s, w.far_val, w.far_idx, w.far_lab, w.far_rows,
+                                   m, d);
+                MTP_LAUNCH_CHECK();
+            }
+            if (cm != nullptr) {
+                MTP_HIP(hipMemcpyAsync(w.red, sw.red_backup, (size_t)red_len * 8, hipMemcpyDeviceToDevice, s));
+                MTP_NCCL(rccl().AllGather(w.far_val, sw.g_val, (size_t)m * 4, kNcclChar, cm->nccl, s));
+                MTP_NCCL(rccl().AllGather(w.far_idx, sw.g_idx, (size_t)m * 8, kNcclChar, cm->nccl, s));
+                MTP_NCCL(rccl().AllGather(w.far_lab, sw.g_lab, (size_t)m * 4, kNcclChar, cm->nccl, s));
+                MTP_NCCL(rccl().AllGather(w.far_rows, sw.g_rows, (size_t)m * d * 4, kNcclChar, cm->nccl, s));
+                hipLaunchKernelGGL(k_far_merge, dim3(1), dim3(1024), 0, s, sw.g_val, sw.g_idx, sw.g_lab, sw.g_rows,
+                                   cm->world * m, m, d, w.far_val, w.far_idx, w.far_lab, w.far_rows);
+                MTP_LAUNCH_CHECK();
+            }
             rc = mtp_apply_relocation_f32(w.red, k, d, m, w.far_val, w.far_lab, w.far_rows, stream);
             if (rc != MTP_OK) return rc;
             MTP_HIP(hipMemsetAsync(w.flags + MTP_FLAG_STATE, 0, 4, s));
@@ -261,7 +502,7 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
     }
     const int n_iter = hflags[MTP_FLAG_N_ITER];
     const int fin = n_iter & 1;  // centres after n_iter M-steps live in parity n_iter & 1
-    if (hflags[MTP_FLAG_STATE] != MTP_STATE_STRICT) {
+    if (hflags[MTP_FLAG_STATE] != MTP_STATE_STRICT && n > 0 && !(options & MTP_LLOYD_NO_FINAL_ESTEP)) {
         // rerun the E-step so that the labels match the final centres (_kmeans.py:736-748).
         // staged / c2 already describe the final centres (written by the last M-step).
         rc = mtp_launch_assign(X, n, d, cbuf[fin], w.staged, w.c2, k, labels_out, nullptr, nullptr, s);
@@ -270,12 +511,59 @@ extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, i
     if (fin != 0) MTP_HIP(hipMemcpyAsync(C_inout, w.c_alt, (size_t)k * d * 4, hipMemcpyDeviceToDevice, s));
     if (inertia_out != nullptr) {
         MTP_HIP(hipMemsetAsync(inertia_out, 0, 8, s));
-        rc = mtp_launch_inertia(X, n, d, cbuf[fin], labels_out, inertia_out, nullptr, s);
-        if (rc != MTP_OK) return rc;
+        if (n > 0) {
+            rc = mtp_launch_inertia(X, n, d, cbuf[fin], labels_out, inertia_out, nullptr, s);
+            if (rc != MTP_OK) return rc;
+        }
+        if (cm != nullptr) MTP_NCCL(rccl().AllReduce(inertia_out, inertia_out, 1, kNcclDouble, kNcclSum, cm->nccl, s));
     }
     if (n_iter_out != nullptr) *n_iter_out = n_iter;
     MTP_HIP(hipStreamSynchronize(s));
+    if (phase_ms_out != nullptr) {
+        // averages over the iterations that ran (an attempt enqueued behind a pause or the end is a no-op)
+        double acc[3] = {0, 0, 0};
+        int cnt = 0;
+        for (size_t e = 0; e + 3 < ev.size() && cnt < n_iter; e += 4, ++cnt) {
+            for (int ph = 0; ph < 3; ++ph) {
+                float ms = 0.f;
+                MTP_HIP(hipEventElapsedTime(&ms, ev[e + ph], ev[e + ph + 1]));
+                acc[ph] += ms;
+            }
+        }
+        for (int ph = 0; ph < 3; ++ph) phase_ms_out[ph] = cnt ? (float)(acc[ph] / cnt) : 0.f;
+    }
     return MTP_OK;
+}
+
+extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int max_iter, double tol_abs,
+                             int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, void *ws,
+                             size_t ws_bytes, void *stream) {
+    MTP_REQUIRE(X && C_inout && labels_out && ws, "mtp_lloyd: null pointer");
+    MTP_REQUIRE(n >= k && k >= 1 && d >= 1 && max_iter >= 1, "mtp_lloyd: bad shape n=%lld k=%d d=%d max_iter=%d",
+                (long long)n, k, d, max_iter);
+    return lloyd_run(nullptr, X, n, 0, d, C_inout, k, max_iter, tol_abs, check_every, labels_out, inertia_out, n_iter_out,
+                     nullptr, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int mtp_lloyd_sharded_f32(const mtp_comm *comm, const float *X_local, int64_t n_local, int64_t row_offset,
+                                     int64_t n_total, int d, float *C_inout, int k, int max_iter, double tol_abs,
+                                     int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out,
+                                     float *phase_ms_out, int options, void *ws, size_t ws_bytes, void *stream) {
+    MTP_REQUIRE(comm != nullptr || (row_offset == 0 && n_local == n_total),
+                "mtp_lloyd_sharded: without a communicator the rank must hold all %lld points", (long long)n_total);
+    MTP_REQUIRE(C_inout && ws && (n_local == 0 || (X_local && labels_out)), "mtp_lloyd_sharded: null pointer");
+    MTP_REQUIRE(n_local >= 0 && row_offset >= 0 && row_offset + n_local <= n_total && n_total >= k && k >= 1 && d >= 1 &&
+                    max_iter >= 1,
+                "mtp_lloyd_sharded: bad shape n_local=%lld offset=%lld n_total=%lld k=%d d=%d max_iter=%d", (long long)n_local,
+                (long long)row_offset, (long long)n_total, k, d, max_iter);
+    if (comm != nullptr) {
+        int dev = -1;
+        MTP_HIP(hipGetDevice(&dev));
+        MTP_REQUIRE(dev == comm->device, "mtp_lloyd_sharded: the communicator was created on device %d, current device is %d",
+                    comm->device, dev);
+    }
+    return lloyd_run(comm, X_local, n_local, row_offset, d, C_inout, k, max_iter, tol_abs, check_every, labels_out,
+                     inertia_out, n_iter_out, phase_ms_out, options, ws, ws_bytes, stream);
 }
 
 // ---- n_init restarts at once: sklearn KMeans.fit's loop over inits (cluster/_kmeans.py:1495-1532) ----

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmtp_accel.so")
 STATE_RUNNING, STATE_STRICT, STATE_TOL, STATE_RELOCATE, STATE_MAXITER = 0, 1, 2, 3, 4
 FLAG_STATE, FLAG_N_ITER, FLAG_N_EMPTY, FLAG_WORDS = 0, 1, 2, 8
 POT_F64, POT_OPENBLAS = 0, 1  # mtp_accel.h MTP_POT_*
+LLOYD_NO_FINAL_ESTEP = 1
 
 _vp, _i64, _i32, _f32, _f64, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_double,
                                     ctypes.c_size_t)
@@ -42,6 +43,12 @@ SIGNATURES = {
     "mtp_apply_relocation_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mtp_lloyd_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _f64, _i32, _vp, _vp, ctypes.POINTER(ctypes.c_int), _vp,
                              _sz, _vp]),
+    "mtp_comm_unique_id": (_i32, [_vp]),
+    "mtp_comm_create": (_i32, [_i32, _i32, _vp, ctypes.POINTER(_vp)]),
+    "mtp_comm_destroy": (_i32, [_vp]),
+    "mtp_lloyd_sharded_workspace_bytes": (_i64, [_i32, _i32, _i64, _i32]),
+    "mtp_lloyd_sharded_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _i32, _i32, _f64, _i32, _vp, _vp,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float), _i32, _vp, _sz, _vp]),
     "mtp_lloyd_batched_workspace_bytes": (_i64, [_i32, _i32, _i32, _i64]),
     "mtp_lloyd_batched_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _f64, _i32, _vp, _vp,
                                      ctypes.POINTER(ctypes.c_int), _vp, _sz, _vp]),

@@ -329,6 +329,67 @@ class ShardedLloyd:
         return self.labels, float(inertia.item()), centers, n_iter
 
 
+class RcclComm:
+    """An RCCL communicator owned by libmtp_accel.so (``mtp_comm_create``), spanning the ranks of the initialised
+    ``torch.distributed`` job: rank 0's unique id travels to the others through one all-reduce of 128 bytes on the
+    existing process group, then every rank joins ``ncclCommInitRank`` on its own GPU.  With it the Lloyd loop runs
+    inside the library (``lloyd_sharded_native``): the per-iteration all-reduce is issued by the library itself, in
+    stream order between its kernels, and the interpreter is out of the loop."""
+
+    def __init__(self, device, group=None):
+        import ctypes
+        self.rank, self.world = world()
+        self.device = device
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (ctypes.c_char * 128)()
+            check(lib().mtp_comm_unique_id(buf), "mtp_comm_unique_id")
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if dist.is_available() and dist.is_initialized() and self.world > 1:
+            t = ident.to(torch.int32)
+            if dist.get_backend(group) != "gloo":
+                t = t.to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)  # zeros everywhere but on rank 0
+            ident = t.cpu().to(torch.uint8)
+        raw = (ctypes.c_char * 128).from_buffer_copy(bytes(ident.numpy().tobytes()))
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            check(lib().mtp_comm_create(self.rank, self.world, raw, ctypes.byref(handle)), "mtp_comm_create")
+        self.handle = handle
+
+    def close(self):
+        if self.handle is not None:
+            with torch.cuda.device(self.device):
+                check(lib().mtp_comm_destroy(self.handle), "mtp_comm_destroy")
+            self.handle = None
+
+
+def lloyd_sharded_native(comm, X_local, C0, row_offset, n_total, max_iter=300, tol_abs=0.0, check_every=1,
+                         want_phase_ms=False, final_estep=True):
+    """sklearn ``_kmeans_single_lloyd`` over row-sharded centred points, the whole loop inside the library
+    (``mtp_lloyd_sharded_f32``: RCCL all-reduce of the packed sums between the library's own kernels).
+    ``comm`` None: one rank holding all points.
+    Returns (labels_local int32, inertia (global), centers [K, D], n_iter[, phase_ms (3 floats)])."""
+    import ctypes
+    n, d = X_local.shape
+    k = C0.shape[0]
+    dev = X_local.device
+    C = C0.clone().contiguous()
+    labels = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
+    inert = torch.zeros(1, dtype=torch.float64, device=dev)
+    ws_bytes = int(lib().mtp_lloyd_sharded_workspace_bytes(k, d, n, comm.world if comm is not None else 1))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    n_iter = ctypes.c_int(0)
+    phase = (ctypes.c_float * 3)() if want_phase_ms else None
+    with torch.cuda.device(dev):
+        check(lib().mtp_lloyd_sharded_f32(comm.handle if comm is not None else None, ptr(X_local) if n else None, n, int(row_offset), int(n_total), d, ptr(C),
+                                          k, int(max_iter), float(tol_abs), int(check_every), ptr(labels) if n else None,
+                                          ptr(inert), ctypes.byref(n_iter), phase, 0 if final_estep else _lib.LLOYD_NO_FINAL_ESTEP,
+                                          ptr(ws), ws_bytes, stream_ptr()), "mtp_lloyd_sharded_f32")
+    out = (labels, float(inert.item()), C, int(n_iter.value))
+    return out + ([float(v) for v in phase],) if want_phase_ms else out
+
+
 def is_same_clustering_sharded(l1, l2, k, collective, group=None):
     """sklearn cluster/_k_means_common.pyx:314-328 over sharded labels: l1 -> l2 is a function iff, for every
     label of l1, the smallest and the largest l2 seen with it -- over all ranks -- coincide."""
@@ -353,7 +414,7 @@ def is_same_clustering_sharded(l1, l2, k, collective, group=None):
 
 def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_iter=300, check_every=1, group=None,
                        force_collectives=False, lagged_steps=0, n_clusters=None, n_init=20, random_state=None,
-                       lloyd_ops=None, seed_ops=None, stats=None):
+                       lloyd_ops=None, seed_ops=None, stats=None, comm=None):
     """sklearn ``KMeans.fit`` over row-sharded, un-centred points (one process per GPU): global mean /
     tolerance by all-reduce of column sums, then
 
@@ -363,6 +424,8 @@ def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_it
         sklearn's rule (cluster/_kmeans.py:1525-1532).  ``random_state`` must denote the SAME stream on every
         rank: an int, or None with ``np.random.seed(s)`` called identically in every process.
 
+    ``comm``: an ``RcclComm``; the Lloyd runs then go through ``mtp_lloyd_sharded_f32`` (loop and all-reduce inside
+    the library) instead of the step-level driver ``ShardedLloyd``.
     Returns dict(labels (local), centers, inertia, n_iter, tol_abs).  ``lloyd_ops`` / ``seed_ops`` / ``stats``
     (precomputed (col_sum, col_sqdev) functions) are test hooks standing in for the HIP kernels."""
     from . import seeding
@@ -386,6 +449,9 @@ def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_it
     sub_rowvec_(Xc, mean32)
 
     def lloyd(c0c):
+        if comm is not None:  # the whole loop inside the library, its own RCCL communicator
+            return lloyd_sharded_native(comm, Xc, c0c, row_offset, n_total, max_iter=max_iter, tol_abs=tol_abs,
+                                        check_every=check_every)
         sl = ShardedLloyd(Xc, c0c, row_offset=row_offset, group=group, force_collectives=force_collectives, ops=lloyd_ops)
         if lagged_steps:  # the first iterations with the flags read one step late (ShardedLloyd.run_fixed)
             sl.run_fixed(min(lagged_steps, max_iter), tol_abs, max_iter)

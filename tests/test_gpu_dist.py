@@ -122,6 +122,52 @@ def test_rccl_one_rank_collectives(which, tmp_path, gpu_device):
     assert np.isclose(float(p["inertia"]), single["inertia"], rtol=1e-9)
 
 
+def _native_worker(rank, port, which, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)
+    sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "tests", "golden")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from pccs_accel import dist as pdist
+    X, C0 = _case(which)
+    comm = pdist.RcclComm(dev)
+    fit = pdist.kmeans_fit_sharded(torch.from_numpy(X).to(dev), X.shape[0], torch.from_numpy(C0).to(dev), row_offset=0,
+                                   check_every=2, comm=comm)
+    # and once with per-phase timing and without the closing E-step (what bench.py calls)
+    Xc = torch.from_numpy(X).to(dev) - torch.from_numpy(X.mean(axis=0, dtype=np.float64).astype(np.float32)).to(dev)
+    C0c = torch.from_numpy(C0).to(dev) - torch.from_numpy(X.mean(axis=0, dtype=np.float64).astype(np.float32)).to(dev)
+    lab5, _, _, it5, phase = pdist.lloyd_sharded_native(comm, Xc.contiguous(), C0c.contiguous(), 0, X.shape[0], max_iter=5,
+                                                        tol_abs=-1.0, check_every=5, want_phase_ms=True, final_estep=False)
+    comm.close()
+    np.savez(os.path.join(out_dir, "native.npz"), labels=fit["labels"].cpu().numpy(), centers=fit["centers"].cpu().numpy(),
+             inertia=fit["inertia"], n_iter=fit["n_iter"], it5=it5, phase=np.asarray(phase))
+    dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+
+
+@pytest.mark.parametrize("which", ["plain", "relocate", "many_empty"])
+def test_in_library_rccl_loop(which, tmp_path, gpu_device):
+    """mtp_lloyd_sharded_f32: the whole Lloyd loop inside the library with its own RCCL communicator
+    (mtp_comm_create: unique id from rank 0, ncclCommInitRank) -- per iteration an in-stream ncclAllReduce of
+    the packed sums, ncclAllGather + merge of the far points for empty clusters, ncclAllReduce of the inertia.
+    One rank on the box's one GPU (RCCL refuses two ranks on one device): same answer as the one-GPU fit."""
+    from pccs_accel import clustering
+    mp.spawn(_native_worker, args=(_free_port(), which, str(tmp_path)), nprocs=1, join=True)
+    X, C0 = _case(which)
+    single = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), C0.shape[0], init=torch.from_numpy(C0))
+    p = np.load(tmp_path / "native.npz")
+    assert int(p["n_iter"]) == single["n_iter"]
+    assert np.array_equal(p["labels"], single["labels"].cpu().numpy())
+    assert np.array_equal(p["centers"], single["centers"].cpu().numpy())
+    assert float(p["inertia"]) == single["inertia"]
+    assert int(p["it5"]) == min(5, single["n_iter"]) or which != "plain"
+    assert p["phase"].shape == (3,) and (p["phase"] >= 0).all() and p["phase"][0] > 0
+
+
 def _pp_case():
     X = datagen.make_encodings(51, 6007, 96, 24, 1500, 900)
     return np.ascontiguousarray(X)
