@@ -245,6 +245,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-ref-configs", action="store_true", help="skip the reference-sized configs (eth, SDD)")
+    ap.add_argument("--loop", choices=["library", "python"], default="library",
+                    help="library: the K timed iterations are ONE call of mtp_lloyd_sharded_f32 (loop, RCCL all-reduce and "
+                         "event timing inside libmtp_accel.so); python: the step-level driver ShardedLloyd.run_fixed "
+                         "(torch.distributed all-reduce, flags read one step late) -- always used under --backend gloo")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo); not a valid scaling result")
@@ -252,6 +256,12 @@ def main():
                     help="rehearsal only: with one rank (launched through torch.distributed.run), create the RCCL "
                          "communicator anyway and issue every collective of the N > 1 path")
     args = ap.parse_args()
+
+    # stdout carries ONE JSON line.  RCCL prints a version banner to the process's stdout when a communicator is
+    # created: everything else written to fd 1 during the run goes to stderr, the JSON line to the real stdout.
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -308,54 +318,103 @@ def main():
     K.sub_rowvec_(X, mean32)
     K.sub_rowvec_(C0, mean32)
 
-    sl = pdist.ShardedLloyd(X, C0, row_offset=lo, force_collectives=args.force_collectives)
     TOL_NEVER = -1.0            # shift_tot <= tol never holds: no early exit inside the timed region
     MAX_IT = 1 << 30
     total_steps = args.warmup + args.steps
+    use_library = args.loop == "library" and args.backend != "gloo" and not args.one_device
+    loop_note = "library (mtp_lloyd_sharded_f32)"
+    comm = None
+    if use_library and collective:
+        try:
+            comm = pdist.RcclComm(device)
+        except Exception as exc:  # noqa: BLE001  (librccl missing / communicator refused: the step-level driver still works)
+            use_library = False
+            loop_note = f"python (library communicator failed: {exc!r})"
+        # every rank must take the same path
+        ok = torch.tensor([1 if use_library else 0], dtype=torch.int32, device=device)
+        allreduce(ok, dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and use_library:
+            use_library = False
+            comm.close()
+            comm = None
+            loop_note = "python (another rank could not create the library communicator)"
 
-    # The loop state (an empty cluster to relocate, as sklearn does; they do occur in the first
-    # iterations of this workload) is read one step late from a pinned snapshot, so the device
-    # never waits for the host (ShardedLloyd.run_fixed).  An attempt enqueued behind a paused
-    # iteration is a no-op and is enqueued again; it stays inside the timed region but is left
-    # out of the per-kernel averages.
-    # The warm-up steps (where this workload's relocations happen) check the flags synchronously, so that
-    # no no-op launches blur the per-kernel averages of a profiled run.
-    n_relocated = 0
-    for _ in range(args.warmup):
-        sl.assign()
-        sl.accumulate()
-        sl.reduce()
-        sl.mstep(TOL_NEVER, MAX_IT)
-        n_relocated += sl.finish_step(TOL_NEVER, MAX_IT)
+    if use_library:
+        # Warm-up call: W iterations from C0 (this workload's empty-cluster relocations happen here), then the timed
+        # call: K iterations from the warmed-up centres as ONE library call -- per iteration E-step, local sums,
+        # in-stream ncclAllReduce of the packed sums (N > 1), M-step finish; the host is out of the loop until the
+        # single flag check after iteration K.  No closing E-step / inertia inside the timed region
+        # (MTP_LLOYD_NO_FINAL_ESTEP): exactly K steps.
+        n_relocated = None
+        _, _, C_w, it_w = pdist.lloyd_sharded_native(comm, X, C0, lo, n, max_iter=max(args.warmup, 1), tol_abs=TOL_NEVER,
+                                                     check_every=1, final_estep=False)
+        barrier()
+        t0 = time.perf_counter()
+        _, _, C_t, it_t, phase = pdist.lloyd_sharded_native(comm, X, C_w, lo, n, max_iter=args.steps, tol_abs=TOL_NEVER,
+                                                            check_every=args.steps, want_phase_ms=True, final_estep=False)
+        barrier()
+        dt = time.perf_counter() - t0
+        if collective:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            allreduce(tmax, dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        if it_t != args.steps:
+            print(f"bench.py: the library loop ran {it_t} iterations, wanted {args.steps}; timing invalid", file=sys.stderr)
+            sys.exit(3)
+        ms_assign, ms_accum, ms_rest = phase
+        noop = []
+        sl = None
+        if comm is not None:
+            comm.close()
+    else:
+        if args.loop == "library" and loop_note.startswith("library"):
+            loop_note = "python (gloo / one-device rehearsal)"
+        elif args.loop == "python":
+            loop_note = "python (ShardedLloyd.run_fixed)"
+        sl = pdist.ShardedLloyd(X, C0, row_offset=lo, force_collectives=args.force_collectives)
+        # The loop state (an empty cluster to relocate, as sklearn does; they do occur in the first
+        # iterations of this workload) is read one step late from a pinned snapshot, so the device
+        # never waits for the host (ShardedLloyd.run_fixed).  An attempt enqueued behind a paused
+        # iteration is a no-op and is enqueued again; it stays inside the timed region but is left
+        # out of the per-kernel averages.
+        # The warm-up steps (where this workload's relocations happen) check the flags synchronously, so that
+        # no no-op launches blur the per-kernel averages of a profiled run.
+        n_relocated = 0
+        for _ in range(args.warmup):
+            sl.assign()
+            sl.accumulate()
+            sl.reduce()
+            sl.mstep(TOL_NEVER, MAX_IT)
+            n_relocated += sl.finish_step(TOL_NEVER, MAX_IT)
 
-    ev = {}
+        ev = {}
 
-    def on_phase(attempt, phase):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        ev.setdefault(attempt, [None] * 4)[phase] = e
+        def on_phase(attempt, phase):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev.setdefault(attempt, [None] * 4)[phase] = e
 
-    barrier()
-    t0 = time.perf_counter()
-    n_reloc_timed, noop, attempts, _ = sl.run_fixed(args.steps, TOL_NEVER, MAX_IT, on_phase=on_phase)
-    barrier()
-    dt = time.perf_counter() - t0
-    n_relocated += n_reloc_timed
-    if collective:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        allreduce(tmax, dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    ev = [ev[a] for a in range(attempts) if a not in set(noop)]
+        barrier()
+        t0 = time.perf_counter()
+        n_reloc_timed, noop, attempts, _ = sl.run_fixed(args.steps, TOL_NEVER, MAX_IT, on_phase=on_phase)
+        barrier()
+        dt = time.perf_counter() - t0
+        n_relocated += n_reloc_timed
+        if collective:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            allreduce(tmax, dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        ev = [ev[a] for a in range(attempts) if a not in set(noop)]
 
-    flags = sl.read_flags()
-    if int(flags[1]) != total_steps or int(flags[0]) != 0:
-        print(f"bench.py: Lloyd loop stopped early (state={flags[0]}, n_iter={flags[1]}, wanted {total_steps}); "
-              "timing invalid", file=sys.stderr)
-        sys.exit(3)
+        flags = sl.read_flags()
+        if int(flags[1]) != total_steps or int(flags[0]) != 0:
+            print(f"bench.py: Lloyd loop stopped early (state={flags[0]}, n_iter={flags[1]}, wanted {total_steps}); "
+                  "timing invalid", file=sys.stderr)
+            sys.exit(3)
 
-    ms_assign = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    ms_accum = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    ms_rest = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+        ms_assign = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        ms_accum = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        ms_rest = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
     ms_step = dt / args.steps * 1e3
     evals_per_s = float(n) * k * d * args.steps / dt
 
@@ -384,14 +443,15 @@ def main():
         "config": {"workload": f"k-means Lloyd iterations, synthetic encodings N={n} D={d} K={k}, fixed init, "
                                f"points sharded over {world} GPU(s)" + (", RCCL all-reduce of sums/counts" if collective else ""),
                    "n": n, "d": d, "k": k, "parallelism": f"points/{world}"},
-        "iters_per_s": args.steps / dt, "clusters_relocated": n_relocated, "noop_attempts_in_timed_region": len(noop),
+        "iters_per_s": args.steps / dt, "loop": loop_note, "clusters_relocated": n_relocated,
+        "noop_attempts_in_timed_region": len(noop),
         "ms_breakdown": {"assign": ms_assign, "accumulate": ms_accum, "allreduce+mstep": ms_rest},
         "roofline": roofline, "roofline_update": roofline_update,
     }
 
     # ---- best-of-K ADE/FDE (second half of the metric), agents sharded, no exchange ----
     if not args.no_eval:
-        del sl
+        sl = None
         elo, ehi = pdist.shard_bounds(args.eval_n, rank, world)
         pred, gt = make_trajectories(ehi - elo, args.eval_k, args.eval_t, seed=4 + rank, device=device)
         reps = 30
@@ -500,7 +560,8 @@ def main():
             "sdd": reference_config("SDD", 17_970, 400, 2_829, 20, device, not args.no_cpu)}
 
     if rank == 0:
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if collective:
         dist.destroy_process_group()
 

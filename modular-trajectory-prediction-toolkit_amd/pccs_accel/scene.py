@@ -127,13 +127,27 @@ def gen_prob(scene_dict, cluster_result, save_dir):
     k = int(cluster_result.max()) + 1 if n else 1
     dense = soft_labels(offsets, ids, cluster_result, k).cpu().numpy()
     off, flat = offsets.cpu().numpy(), ids.cpu().numpy()
-    res_class, res_prob = [], []
-    for i in range(n):
-        seen = np.concatenate(([cluster_result[i]], cluster_result[flat[off[i]:off[i + 1]]]))
-        _, first = np.unique(seen, return_index=True)
-        classes = seen[np.sort(first)].astype(int)
-        res_class.append(classes)
-        res_prob.append(dense[i, classes].astype(float))
+    # first-seen order of the classes of [own cluster, neighbours...] for all samples in one pass (the reference
+    # walks a dict per sample, data_process.py:176-186): one flat sequence ordered by (sample, position), a stable
+    # sort by (sample, class) puts every pair's first occurrence first, and those first occurrences, put back in
+    # sequence order, are the classes as the reference lists them
+    counts = np.diff(off) + 1
+    start = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=start[1:])
+    sample = np.repeat(np.arange(n, dtype=np.int64), counts)
+    seq = np.empty(int(start[-1]), dtype=np.int64)
+    seq[start[:-1]] = cluster_result                      # position 0: the sample's own cluster
+    nb_pos = np.ones(seq.size, dtype=bool)
+    nb_pos[start[:-1]] = False
+    seq[nb_pos] = cluster_result[flat]                    # then its neighbours, in list order
+    key = sample * k + seq
+    order = np.argsort(key, kind="stable")
+    sk = key[order]
+    first = np.sort(order[np.concatenate(([True], sk[1:] != sk[:-1]))]) if seq.size else np.zeros(0, dtype=np.int64)
+    f_sample, f_class = sample[first], seq[first].astype(int)
+    cuts = np.cumsum(np.bincount(f_sample, minlength=n))[:-1]
+    res_class = np.split(f_class, cuts)
+    res_prob = np.split(dense[f_sample, f_class].astype(float), cuts)
     with open(os.path.join(save_dir, "probabilities.pkl"), "wb") as f:
         pickle.dump((res_class, res_prob), f, 4)
     return res_class, res_prob

@@ -129,6 +129,16 @@ def main():
     labels = torch.randint(0, 200, (n,), generator=g, device=dev).to(torch.int32)
     ms = timed(lambda: scene.soft_labels(offsets, ids, labels, 200))
     emit("k_soft_labels (K=200)", ms, bytes=n * 200 * 8.0 + ids.numel() * 12.0 + n * 20.0)
+    # the host side of the same call site: neighbour dict -> CSR, kernel, first-seen class lists, pickle
+    import tempfile
+    scene_dict = scene._csr_to_dict(offsets, ids)
+    lab_np = labels.cpu().numpy()
+    with tempfile.TemporaryDirectory() as tmp:
+        t0 = time.perf_counter()
+        scene.gen_prob(scene_dict, lab_np, tmp)
+        host_ms = (time.perf_counter() - t0) * 1e3
+    emit("gen_prob end to end (dict -> CSR, k_soft_labels, class lists in first-seen order, probabilities.pkl)", host_ms,
+         n=n, nnz=int(ids.numel()))
 
 
 if __name__ == "__main__":
