@@ -3,6 +3,7 @@
 // produces identical labels.  Build: make -C tools   Run (GPU box): tools/assign_tune [N] [K]
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "assign_kernel.h"
@@ -24,6 +25,8 @@ __global__ void k_fill(float *p, size_t n, unsigned seed) {
     }
 }
 
+static MtpBatchStride g_bs = mtp_no_batch();  // restarts: same points, own centroid image and labels
+
 struct Variant {
     const char *name;
     void (*launch)(const float *, int64_t, const float *, int, int32_t *, hipStream_t);
@@ -40,8 +43,8 @@ void launch_v(const float *X, int64_t n, const float *staged, int k, int32_t *la
         set = true;
     }
     const int64_t ppb = WPB * 32 * PT;
-    hipLaunchKernelGGL((k_assign_mfma<D, PT, CTW, WPB, WPS, EPI, LG, PRIO>), dim3((unsigned)((n + ppb - 1) / ppb)), dim3(64 * WPB), lds, s, X,
-                       n, staged, (k + 31) / 32, labels, nullptr, nullptr, mtp_no_batch());
+    hipLaunchKernelGGL((k_assign_mfma<D, PT, CTW, WPB, WPS, EPI, LG, PRIO>), dim3((unsigned)((n + ppb - 1) / ppb), g_bs.batch), dim3(64 * WPB), lds, s, X,
+                       n, staged, (k + 31) / 32, labels, nullptr, nullptr, g_bs);
     CK(hipGetLastError());
 }
 
@@ -55,46 +58,85 @@ void launch_pipe(const float *X, int64_t n, const float *staged, int k, int32_t 
         set = true;
     }
     const int64_t ppb = WPB * 32;
-    hipLaunchKernelGGL((k_assign_mfma_pipe<D, WPB, WPS, LG>), dim3((unsigned)((n + ppb - 1) / ppb)), dim3(64 * WPB), lds, s, X, n,
-                       staged, mtp_n_tiles(k), labels, nullptr, nullptr, mtp_no_batch());
+    hipLaunchKernelGGL((k_assign_mfma_pipe<D, WPB, WPS, LG>), dim3((unsigned)((n + ppb - 1) / ppb), g_bs.batch), dim3(64 * WPB), lds, s, X, n,
+                       staged, mtp_n_tiles(k), labels, nullptr, nullptr, g_bs);
     CK(hipGetLastError());
 }
 
-int main(int argc, char **argv) {
-    const int64_t n = argc > 1 ? atoll(argv[1]) : 10000000;
-    const int k = argc > 2 ? atoi(argv[2]) : 1024;
-    constexpr int D = 128;
+static unsigned *g_tickets = nullptr;
+// SMALL: small units per workgroup at the end of the queue (-1: everything in small units)
+template <int D, int WPS, int SMALL>
+void launch_queue(const float *X, int64_t n, const float *staged, int k, int32_t *labels, hipStream_t s) {
+    const size_t lds = 2 * (size_t)2 * mtp_tile_floats(D) * sizeof(float);
+    static bool set = false;
+    static int cus = 0;
+    if (!set) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign_mfma_queue<D, WPS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, 0));
+        cus = prop.multiProcessorCount;
+        set = true;
+    }
+    const int grid = 2 * cus;
+    const int64_t T4 = (n + 127) / 128;
+    int64_t small = SMALL < 0 ? T4 : ((int64_t)SMALL * grid + g_bs.batch - 1) / g_bs.batch;
+    if (small > T4) small = T4;
+    MtpAssignQueue q;
+    q.ticket = g_tickets;
+    q.big_per_restart = (int)((T4 - small) / 2);
+    q.small_per_restart = (int)(T4 - 2 * (int64_t)q.big_per_restart);
+    hipLaunchKernelGGL((k_assign_mfma_queue<D, WPS>), dim3(grid), dim3(512), lds, s, X, n, staged, (k + 31) / 32, labels,
+                       nullptr, nullptr, g_bs, q, nullptr);
+    CK(hipGetLastError());
+}
+
+template <int D>
+int run(int64_t n, int k, const char *filter, int batch) {
     float *X, *C, *staged, *c2;
     int32_t *labels, *ref;
     CK(hipMalloc(&X, n * D * 4));
     CK(hipMalloc(&C, (size_t)k * D * 4));
-    CK(hipMalloc(&staged, (size_t)mtp_n_tiles(k) * mtp_tile_floats(D) * 4));
+    const size_t image = (size_t)mtp_n_tiles(k) * mtp_tile_floats(D);
+    CK(hipMalloc(&staged, image * 4 * batch));
     CK(hipMalloc(&c2, k * 4));
-    CK(hipMalloc(&labels, n * 4));
-    CK(hipMalloc(&ref, n * 4));
+    CK(hipMalloc(&labels, n * 4 * batch));
+    CK(hipMalloc(&ref, n * 4 * batch));
+    CK(hipMalloc(&g_tickets, 256));
+    CK(hipMemset(g_tickets, 0, 256));
     k_fill<<<4096, 256>>>(X, (size_t)n * D, 1);
     k_fill<<<256, 256>>>(C, (size_t)k * D, 7);
-    if (mtp_launch_stage_centers(C, k, D, staged, c2, nullptr, 0) != 0) { printf("stage failed\n"); return 1; }
+    for (int b = 0; b < batch; ++b)  // every restart gets the same centroids (the timing does not care)
+        if (mtp_launch_stage_centers(C, k, D, staged + b * image, c2, nullptr, 0) != 0) { printf("stage failed\n"); return 1; }
+    g_bs = mtp_no_batch();
+    g_bs.batch = batch;
+    g_bs.staged = image;
+    g_bs.labels = (size_t)n;
     CK(hipDeviceSynchronize());
 
     std::vector<Variant> vs = {
         {"PT1 CTW2 WPB8 WPS4 (product)", launch_v<D, 1, 2, 8, 4, true>, true},
+        {"QUEUE small 0", launch_queue<D, 4, 0>, true},
+        {"QUEUE small 1/wg", launch_queue<D, 4, 1>, true},
+        {"QUEUE small 2/wg", launch_queue<D, 4, 2>, true},
+        {"QUEUE small 3/wg", launch_queue<D, 4, 3>, true},
+        {"QUEUE small 4/wg", launch_queue<D, 4, 4>, true},
+        {"QUEUE all small", launch_queue<D, 4, -1>, true},
         {"PIPE WPB8 WPS4", launch_pipe<D, 8, 4>, true},
-        {"PIPE WPB8 WPS4 LG16", launch_pipe<D, 8, 4, 16>, true},
-        {"PIPE WPB8 WPS3", launch_pipe<D, 8, 3>, true},
-        {"PIPE WPB4 WPS4", launch_pipe<D, 4, 4>, true},
         {"PT1 CTW2 WPB8 WPS4 LG16", launch_v<D, 1, 2, 8, 4, true, 16>, true},
-        {"PT1 CTW2 WPB8 WPS4 LG4", launch_v<D, 1, 2, 8, 4, true, 4>, true},
-        {"PT1 CTW2 WPB8 WPS4 PRIO", launch_v<D, 1, 2, 8, 4, true, 8, true>, true},
         {"PT1 CTW2 WPB8 WPS4 LG16 PRIO", launch_v<D, 1, 2, 8, 4, true, 16, true>, true},
-        {"PT2 CTW2 WPB4 WPS2", launch_v<D, 2, 2, 4, 2, true>, true},
         {"PT1 CTW4 WPB16 WPS4", launch_v<D, 1, 4, 16, 4, true>, true},
         {"PT1 CTW1 WPB8 WPS4", launch_v<D, 1, 1, 8, 4, true>, true},
         {"PT1 CTW2 WPB8 WPS4 no-epi", launch_v<D, 1, 2, 8, 4, false>, false},
         {"PT1 CTW1 WPB4 WPS4", launch_v<D, 1, 1, 4, 4, true>, true},
         {"PT1 CTW2 WPB16 WPS4", launch_v<D, 1, 2, 16, 4, true>, true},
-        {"PT1 CTW2 WPB8 WPS3", launch_v<D, 1, 2, 8, 3, true>, true},
     };
+    if (filter != nullptr) {  // keep the variants whose name contains it (the product variant always stays)
+        std::vector<Variant> keep;
+        for (size_t v = 0; v < vs.size(); ++v)
+            if (v == 0 || strstr(vs[v].name, filter)) keep.push_back(vs[v]);
+        vs = keep;
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -102,11 +144,12 @@ int main(int argc, char **argv) {
     std::vector<std::vector<float>> ms(vs.size());
     vs[0].launch(X, n, staged, k, ref, 0);
     CK(hipDeviceSynchronize());
-    std::vector<int32_t> href(n), hl(n);
-    CK(hipMemcpy(href.data(), ref, n * 4, hipMemcpyDeviceToHost));
+    const int64_t nl = n * batch;
+    std::vector<int32_t> href(nl), hl(nl);
+    CK(hipMemcpy(href.data(), ref, nl * 4, hipMemcpyDeviceToHost));
     for (int r = 0; r < rounds; ++r) {
         for (size_t v = 0; v < vs.size(); ++v) {
-            CK(hipMemset(labels, 0xff, n * 4));
+            CK(hipMemset(labels, 0xff, nl * 4));
             CK(hipEventRecord(e0, 0));
             vs[v].launch(X, n, staged, k, labels, 0);
             CK(hipEventRecord(e1, 0));
@@ -115,14 +158,14 @@ int main(int argc, char **argv) {
             CK(hipEventElapsedTime(&t, e0, e1));
             ms[v].push_back(t);
             if (r == 0 && vs[v].epi) {
-                CK(hipMemcpy(hl.data(), labels, n * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hl.data(), labels, nl * 4, hipMemcpyDeviceToHost));
                 size_t bad = 0;
-                for (int64_t i = 0; i < n; ++i) bad += hl[i] != href[i];
+                for (int64_t i = 0; i < nl; ++i) bad += hl[i] != href[i];
                 if (bad) printf("  !! %s: %zu label mismatches vs product variant\n", vs[v].name, bad);
             }
         }
     }
-    const double flop = 2.0 * n * k * D;
+    const double flop = 2.0 * n * k * D * batch;
     for (size_t v = 0; v < vs.size(); ++v) {
         float mn = 1e30f, sum = 0;
         for (int r = 1; r < rounds; ++r) { mn = ms[v][r] < mn ? ms[v][r] : mn; sum += ms[v][r]; }
@@ -131,4 +174,16 @@ int main(int argc, char **argv) {
                flop / (mn * 1e-3) / 1e12, flop / (mn * 1e-3) / 1e12 / 157.3 * 100);
     }
     return 0;
+}
+
+// tools/assign_tune [N] [K] [name filter | -] [D: 64 | 96 | 128] [restarts]
+int main(int argc, char **argv) {
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 10000000;
+    const int k = argc > 2 ? atoi(argv[2]) : 1024;
+    const char *filter = argc > 3 && strcmp(argv[3], "-") != 0 ? argv[3] : nullptr;
+    const int d = argc > 4 ? atoi(argv[4]) : 128;
+    const int batch = argc > 5 ? atoi(argv[5]) : 1;
+    if (d == 96) return run<96>(n, k, filter, batch);
+    if (d == 64) return run<64>(n, k, filter, batch);
+    return run<128>(n, k, filter, batch);
 }
