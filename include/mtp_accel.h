@@ -72,6 +72,15 @@ int mtp_col_sums_f32(const float *X, int64_t n, int d, double *col_sum, void *st
 int mtp_col_sqdev_f32(const float *X, int64_t n, int d, const double *mean, double *col_sqdev, void *stream);
 int mtp_sub_rowvec_f32(float *X, int64_t n, int d, const float *vec, void *stream);
 
+/* The same column statistics in NumPy's own float order: out[c] = the float32 sum over the rows, added one
+ * row after the other (what np.add.reduce(X, axis=0) does on a C-ordered float32 array), of X[i][c] when
+ * center is NULL, else of (X[i][c] - center[c])^2 with the difference and the square rounded to float
+ * (numpy/_core/_methods.py _var: x = arr - arrmean; x = x * x).  With these the host forms
+ * X.mean(axis=0) and np.mean(np.var(X, axis=0)) * tol exactly as sklearn cluster/_kmeans.py:279-287 and
+ * :1478-1481 do, bit for bit, so that the centred points and the tolerance are the reference's.
+ * out is overwritten ([d] floats). */
+int mtp_col_seqsum_f32(const float *X, int64_t n, int d, const float *center, float *out, void *stream);
+
 /* E-step: labels[i] = argmin_j (||c_j||^2 - 2 x_i.c_j), strict '<', lowest index wins.
  * Replaces sklearn cluster/_k_means_lloyd.pyx:168-213 (_update_chunk_dense, E part) -- the
  * "nearest-modality assignment" of PCCSNet/train_steps.py:357.

@@ -407,6 +407,95 @@ extern "C" int mtp_col_sqdev_f32(const float *X, int64_t n, int d, const double 
     return launch_col_stats(true, X, n, d, mean, col_sqdev, mtp_stream(stream));
 }
 
+// ------------------------------------------------------------------------------------------
+// Column sums in NumPy's float order.  np.add.reduce(X, axis=0) on a C-ordered float32 [n, d] array adds the
+// rows one after the other into d float accumulators (checked against NumPy by the CPU suite through
+// oracle.c's restatement), and X.mean(axis=0) / np.var(X, axis=0) are built on it (numpy/_core/_methods.py
+// _mean, _var): a sum in another order moves the column means by an ulp, the centred points with them, and
+// a few points per 7e4 change cluster.  One chain of n dependent float additions per column: the kernel is
+// bound by the addition latency (~n x 6 clocks), not by memory.  A workgroup owns 16 columns; all 256
+// threads bring tiles of 512 rows x 16 columns to LDS (double buffered, the next tile's loads are in flight
+// while this one is walked), 16 lanes walk them.
+// SQ: the summand is (x - center[c])^2 formed in float like NumPy's x = arr - arrmean; x * x.
+// ------------------------------------------------------------------------------------------
+constexpr int SEQ_COLS = 16, SEQ_ROWS = 512;
+
+template <bool SQ>
+__global__ __launch_bounds__(256) void k_col_seqsum(const float *__restrict__ X, int64_t n, int d,
+                                                    const float *__restrict__ center, float *out) {
+    __shared__ float tile[2][SEQ_ROWS * SEQ_COLS];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * SEQ_COLS;
+    const int lc = tid & (SEQ_COLS - 1), lr = tid >> 4;  // this thread loads column c0 + lc of rows lr, lr + 16, ...
+    const bool col_ok = c0 + lc < d;
+    constexpr int PER = SEQ_ROWS / 16;  // loads per thread and tile
+    float v[PER];
+    auto load = [&](int64_t r0) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int64_t r = r0 + lr + 16 * e;
+            v[e] = (col_ok && r < n) ? X[r * d + c0 + lc] : 0.f;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) tile[buf][(lr + 16 * e) * SEQ_COLS + lc] = v[e];
+    };
+    const float mu = (SQ && col_ok) ? center[c0 + lc] : 0.f;
+    float acc = 0.f;
+    load(0);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t r0 = 0; r0 < n; r0 += SEQ_ROWS) {
+        const bool more = r0 + SEQ_ROWS < n;
+        if (more) load(r0 + SEQ_ROWS);
+        if (tid < SEQ_COLS) {
+            const int rows = (int)((n - r0) < SEQ_ROWS ? (n - r0) : SEQ_ROWS);
+            const float *t = tile[buf] + tid;
+            int r = 0;
+            for (; r + 32 <= rows; r += 32) {
+                float w[32];
+#pragma unroll
+                for (int e = 0; e < 32; ++e) w[e] = t[(r + e) * SEQ_COLS];
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    if (SQ) {
+                        const float x = w[e] - mu;
+                        acc = acc + x * x;
+                    } else {
+                        acc = acc + w[e];
+                    }
+                }
+            }
+            for (; r < rows; ++r) {
+                const float w = t[r * SEQ_COLS];
+                if (SQ) {
+                    const float x = w - mu;
+                    acc = acc + x * x;
+                } else {
+                    acc = acc + w;
+                }
+            }
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (tid < SEQ_COLS && col_ok) out[c0 + tid] = acc;
+}
+
+extern "C" int mtp_col_seqsum_f32(const float *X, int64_t n, int d, const float *center, float *out, void *stream) {
+    MTP_REQUIRE(X && out && n >= 0 && d >= 1, "mtp_col_seqsum: bad arguments");
+    const unsigned blocks = (unsigned)((d + SEQ_COLS - 1) / SEQ_COLS);
+    if (center != nullptr)
+        hipLaunchKernelGGL(k_col_seqsum<true>, dim3(blocks), dim3(256), 0, mtp_stream(stream), X, n, d, center, out);
+    else
+        hipLaunchKernelGGL(k_col_seqsum<false>, dim3(blocks), dim3(256), 0, mtp_stream(stream), X, n, d, center, out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
 __global__ __launch_bounds__(256) void k_sub_rowvec(float *X, int64_t total, int d, const float *__restrict__ vec) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
         X[e] = X[e] - vec[e % d];

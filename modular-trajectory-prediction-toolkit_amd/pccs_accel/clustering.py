@@ -41,10 +41,27 @@ def _as_device_f32(data, device=None):
     return t.to(device=device, dtype=torch.float32, copy=True).contiguous()
 
 
-def tolerance_and_mean(X, tol):
-    """(tol_abs, mean32) as KMeans.fit computes them before centring
-    (sklearn cluster/_kmeans.py:279-287, :1478-1481): column means and variances, in double."""
-    n = X.shape[0]
+def tolerance_and_mean(X, tol, order="numpy"):
+    """(tol_abs, mean32) as KMeans.fit computes them before centring (sklearn cluster/_kmeans.py:279-287,
+    :1478-1481): ``X.mean(axis=0)`` and ``np.mean(np.var(X, axis=0)) * tol``.
+
+    ``order="numpy"``: the column sums are taken in NumPy's own float32 order (row after row,
+    ``mtp_col_seqsum_f32``) and divided by NumPy on the host exactly as numpy/_core/_methods.py does, so the
+    mean, the centred points and the tolerance are the reference's bit for bit.  ``order="f64"``: double sums
+    (parallel, independent of how the rows are split; what the sharded fit uses): the mean can differ by an
+    ulp, which moves a few boundary points per 7e4."""
+    n, d = X.shape
+    if order == "numpy":
+        s = K.col_seqsum(X).cpu().numpy()
+        mean = np.true_divide(s, np.intp(n), out=s, casting="unsafe")  # _mean: ret / rcount into the float32 array
+        mean32 = torch.from_numpy(mean).to(X.device)
+        if tol == 0:
+            return 0.0, mean32
+        sq = K.col_seqsum(X, mean32).cpu().numpy()
+        var = np.true_divide(sq, np.intp(n), out=sq, casting="unsafe")  # _var
+        return float(np.mean(var) * tol), mean32
+    if order != "f64":
+        raise ValueError(f"order must be 'numpy' or 'f64', got {order!r}")
     col_sum = K.col_sums(X)
     mean64 = col_sum / n
     sqdev = K.col_sqdev(X, mean64)
@@ -67,7 +84,7 @@ def restart_batch(n, d, k, n_init):
 
 
 def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, max_iter=300, tol=1e-4,
-               x_mean=None, check_every=None, batch=None, pot_order="openblas", restarts_out=None):
+               x_mean=None, check_every=None, batch=None, pot_order="openblas", restarts_out=None, stats_order="numpy"):
     """sklearn ``KMeans(n_clusters, n_init=n_init, init=init).fit(X)`` on one MI355X.
 
     X: float32 device tensor [N, D] (not modified).  ``init``: 'k-means++' or a [K, D] array /
@@ -75,6 +92,7 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
     global RandomState, so ``np.random.seed(s)`` before the call pins it, as with the
     reference), an int, or a RandomState.  ``x_mean`` overrides the column mean (tests).
     ``batch``: restarts per launch (default: ``restart_batch``); the result does not depend on it.
+    ``stats_order``: float order of the column mean / variance (``tolerance_and_mean``).
     ``pot_order``: summation order of the k-means++ potentials (``seeding``: "openblas" reproduces the
     reference stack's seeds, "f64" sums in double).  ``restarts_out``: a list that receives one
     dict(indices, inertia, n_iter, labels) per restart, in order (tests / diagnostics).
@@ -96,7 +114,7 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
         rs = random_state
 
     X = X.contiguous()
-    tol_abs, mean32 = tolerance_and_mean(X, tol)
+    tol_abs, mean32 = tolerance_and_mean(X, tol, stats_order)
     if x_mean is not None:
         mean32 = torch.as_tensor(x_mean, dtype=torch.float32, device=X.device).contiguous()
     Xc = X.clone()

@@ -8,6 +8,7 @@ Mirrors (same names, arguments, files and return values)
 called from PCCSNet/train_steps.py:368.  The O(n^2)-per-scene pair test and the histogram run in
 libmtp_accel.so (csrc/scene.hip); this file sequences them and keeps the reference's file formats.
 """
+import itertools
 import os
 import pickle
 
@@ -93,10 +94,11 @@ def _csr_to_dict(offsets, ids):
 
 
 def _dict_to_csr(scene_dict, n, device):
-    counts = np.fromiter((len(scene_dict[i]) for i in range(n)), dtype=np.int64, count=n)
+    lists = [scene_dict[i] for i in range(n)]
+    counts = np.fromiter(map(len, lists), dtype=np.int64, count=n)
     off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(counts, out=off[1:])
-    flat = np.fromiter((j for i in range(n) for j in scene_dict[i]), dtype=np.int64, count=int(off[-1]))
+    flat = np.fromiter(itertools.chain.from_iterable(lists), dtype=np.int64, count=int(off[-1]))
     return torch.from_numpy(off).to(device), torch.from_numpy(flat).to(device)
 
 
@@ -145,9 +147,12 @@ def gen_prob(scene_dict, cluster_result, save_dir):
     sk = key[order]
     first = np.sort(order[np.concatenate(([True], sk[1:] != sk[:-1]))]) if seq.size else np.zeros(0, dtype=np.int64)
     f_sample, f_class = sample[first], seq[first].astype(int)
-    cuts = np.cumsum(np.bincount(f_sample, minlength=n))[:-1]
-    res_class = np.split(f_class, cuts)
-    res_prob = np.split(dense[f_sample, f_class].astype(float), cuts)
+    cuts = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(f_sample, minlength=n), out=cuts[1:])
+    f_prob = dense[f_sample, f_class].astype(float)
+    res_class = [f_class[cuts[i]:cuts[i + 1]] for i in range(n)]  # (np.split costs five times as much)
+    res_prob = [f_prob[cuts[i]:cuts[i + 1]] for i in range(n)]
+    # what is left is the reference's file format: pickling 2 n small arrays takes longer than everything above
     with open(os.path.join(save_dir, "probabilities.pkl"), "wb") as f:
         pickle.dump((res_class, res_prob), f, 4)
     return res_class, res_prob

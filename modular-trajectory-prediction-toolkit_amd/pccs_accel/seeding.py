@@ -182,20 +182,27 @@ def _first_argmin(v):
 
 
 def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, group=None, ops=None,
-                            force_collectives=False):
+                            force_collectives=False, packed=True):
     """k-means++ (sklearn cluster/_kmeans.py:174-272, unit weights) for ``len(draws)`` restarts in lock
     step over ROW-SHARDED centred points: this rank holds rows [row_offset, row_offset + n_local) of
-    the n_total.  ``draws``: one ``draw()`` result per restart, identical on every rank.
+    the n_total (consecutive blocks in rank order).  ``draws``: one ``draw()`` result per restart,
+    identical on every rank.
 
-    Per new centre: (1) the ranks' totals of their closest-distance rows (= their part of the chosen
-    candidate's potential) are all-gathered and give each rank its offset into the global
-    ``stable_cumsum``; (2) the number of local cumulative sums below each draw is counted
-    (``mtp_kpp_count_below_f32``, no cumulative sum is materialised) and all-reduced: the sum IS
-    sklearn's ``searchsorted(cumsum, rand)``; (3) the owners contribute the candidate rows to one
-    all-reduce; (4) each rank computes the candidates' distances to its points with the fp64
-    matrix-pipe kernel and its part of the potentials; one all-reduce of [B, L] doubles; (5) every
-    rank picks the same best candidate.  Returns (centres float32 [B, K, D], indices int64 [B, K]),
-    replicated.  Needs D % 16 == 0 and at most 8 local trials (K <= 1096)."""
+    Two exchanges per new centre (``packed``), both all-gathers of a few KB per rank:
+      (A) every rank counts its cumulative sums below each draw (``mtp_kpp_count_below_f32``; the draw is
+          taken relative to the rank's first row with the lower ranks' totals, known from (B) of the step
+          before; no cumulative sum is materialised) and sends [count | the row it would contribute] --
+          its row number ``min(count, n_local - 1)`` -- per (restart, trial).  The sum of the counts IS
+          sklearn's ``searchsorted(cumsum, rand)``, it names the owning rank, and the owner's row is
+          already there.  (In exact arithmetic the owner's count is the candidate's local row number; if
+          rounding between a rank's total and its cumulative sums ever breaks that, every rank sees it in the
+          same gathered data, and the seeding is redone with the row fetched by index, ``packed=False``.)
+      (B) each rank computes the candidates' distances to its points with the fp64 matrix-pipe kernel; the
+          ranks' parts of the [B, L] potentials are gathered and added in rank order: the totals, and every
+          rank's part of the chosen row's total for the next step's (A).
+    ``packed=False``: three collectives per centre (counts all-reduced, rows fetched by index, potentials as in (B)).
+    Returns (centres float32 [B, K, D], indices int64 [B, K]), replicated.  Needs D % 16 == 0 and at most 8
+    local trials (K <= 1096)."""
     from . import dist as pdist
     if ops is None:
         ops = DeviceSeedOps()
@@ -212,6 +219,17 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
         raise ValueError("every restart needs at least n_clusters - 1 rows of uniform draws of one width")
     ar = torch.arange(b, device=dev)
 
+    def gather(t):
+        """[W, ...]: every rank's t, in rank order."""
+        return pdist.all_gather_cat(t[None].contiguous(), ws, group)
+
+    if collective:
+        meta = gather(torch.tensor([lo, n_local], dtype=torch.int64, device=dev))  # [W, 2]
+        los, sizes = meta[:, 0].contiguous(), meta[:, 1].contiguous()
+        his = (los + sizes).contiguous()
+        if int(los[0]) != 0 or int(his[-1]) != n_total or bool((los[1:] != his[:-1]).any()):
+            raise ValueError("the ranks must hold consecutive row blocks of the n_total rows, in rank order")
+
     def fetch_rows(idx):
         """X[idx] for GLOBAL row indices idx [B, m] -> [B, m, D] on every rank (owners contribute, one all-reduce)."""
         if n_local:
@@ -225,34 +243,61 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
             pdist.all_reduce_sum(rows, group)
         return rows
 
+    def total_potentials(pot):
+        """(global potentials [B, m], every rank's part [W, B, m]); parts added in rank order."""
+        if not collective:
+            return pot, pot[None]
+        parts = gather(pot)
+        tot = parts[0].clone()
+        for r in range(1, parts.shape[0]):
+            tot += parts[r]
+        return tot, parts
+
     yy = ops.row_sqnorm(X_local)
     indices = torch.empty((b, n_clusters), dtype=torch.int64, device=dev)
     rows, pot = ops.candidate_dists(X_local, yy, fetch_rows(ids0[:, None]), None)
-    local_tot = pot[:, 0].clone()  # this rank's part of the potential = the total of its closest row
-    if collective:
-        pdist.all_reduce_sum(pot, group)
+    pot, parts = total_potentials(pot)
+    lower_tot = parts[:rank, :, 0].sum(dim=0)  # the lower ranks' totals of the closest-distance row
     closest = rows[:, 0, :].contiguous()
     cur_pot = pot[:, 0].to(torch.float32)  # sklearn's potentials are float32
     indices[:, 0] = ids0
+    bad = torch.zeros((), dtype=torch.bool, device=dev)
     if n_clusters > 1:
         u = torch.from_numpy(np.ascontiguousarray(np.stack([uu for _, uu in draws]))).to(dev)  # [B, K-1, L]
     for c in range(1, n_clusters):
         rand = u[:, c - 1, :] * cur_pot.to(torch.float64)[:, None]
         if collective:
-            every = pdist.all_gather_cat(local_tot[None].contiguous(), ws, group)  # [W, B]
-            rand = rand - every[:rank].sum(dim=0)[:, None]  # the draw relative to this rank's first row
+            rand = rand - lower_tot[:, None]  # the draw relative to this rank's first row
         cnt = ops.count_below(closest, rand)  # cumulative sums < draw, per (restart, trial)
-        if collective:
+        if not collective:
+            idx = cnt.clamp(max=n_total - 1)
+            cand = X_local[idx]
+        elif packed:
+            l = cnt.shape[1]
+            payload = torch.zeros((b, l, 1 + d), dtype=torch.float64, device=dev)
+            payload[..., 0] = cnt.to(torch.float64)
+            if n_local:
+                payload[..., 1:] = X_local[cnt.clamp(max=n_local - 1)].to(torch.float64)
+            every = gather(payload)  # [W, B, L, 1 + D]
+            cnts = every[..., 0].to(torch.int64)
+            idx = cnts.sum(dim=0).clamp(max=n_total - 1)
+            owner = torch.searchsorted(his, idx, right=True).clamp(max=ws - 1)  # first rank whose block ends beyond idx
+            sent = torch.minimum(cnts.gather(0, owner[None])[0], sizes[owner] - 1)  # the row number the owner sent
+            bad |= (sent != idx - los[owner]).any()
+            cand = every.gather(0, owner[None, :, :, None].expand(1, b, l, 1 + d))[0][..., 1:].to(torch.float32)
+        else:
             pdist.all_reduce_sum(cnt, group)
-        idx = cnt.clamp(max=n_total - 1)
-        rows, pot = ops.candidate_dists(X_local, yy, fetch_rows(idx), closest)
-        pot_local = pot.clone() if collective else pot
-        if collective:
-            pdist.all_reduce_sum(pot, group)
+            idx = cnt.clamp(max=n_total - 1)
+            cand = fetch_rows(idx)
+        rows, pot = ops.candidate_dists(X_local, yy, cand.contiguous(), closest)
+        pot, parts = total_potentials(pot)
         pot32 = pot.to(torch.float32)
         best = _first_argmin(pot32)
         closest = rows[ar, best].contiguous()
         cur_pot = pot32[ar, best]
-        local_tot = pot_local[ar, best]
+        lower_tot = parts[:rank, ar, best].sum(dim=0)
         indices[:, c] = idx[ar, best]
+    if collective and packed and bool(bad):
+        return kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, group=group, ops=ops,
+                                       force_collectives=force_collectives, packed=False)
     return fetch_rows(indices), indices

@@ -360,3 +360,24 @@ float orc_sum_sdot(const float *x, int64_t n) {
     for (int64_t i = n1; i < n; ++i) dot += (double)x[i];
     return (float)dot;
 }
+
+/* np.add.reduce(X, axis=0) on a C-ordered float32 [n, d] array: d float accumulators, the rows added one
+ * after the other (numpy/_core/src/umath/reduction.c: the reduced axis is the outer loop of the iterator);
+ * with `center`, the summand of numpy/_core/_methods.py _var: x = arr - arrmean; x = x * x, in float.
+ * X.mean(axis=0) and np.var(X, axis=0) divide these sums by n (sklearn cluster/_kmeans.py:279-287, :1478-1481).
+ * Checked against NumPy itself in tests/test_oracle_golden.py. */
+void orc_col_seqsum_f32(const float *X, int64_t n, int d, const float *center, float *out) {
+    for (int c = 0; c < d; ++c) out[c] = 0.f;
+    for (int64_t i = 0; i < n; ++i) {
+        const float *x = X + i * d;
+        if (center) {
+            for (int c = 0; c < d; ++c) {
+                volatile float t = x[c] - center[c]; /* volatile: keep the two float roundings apart */
+                volatile float q = t * t;
+                out[c] = out[c] + q;
+            }
+        } else {
+            for (int c = 0; c < d; ++c) out[c] = out[c] + x[c];
+        }
+    }
+}

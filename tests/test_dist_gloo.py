@@ -319,7 +319,7 @@ def _seed_case():
     return np.ascontiguousarray(X - X.mean(axis=0))
 
 
-def _seed_worker(rank, world, port, out_dir):
+def _seed_worker(rank, world, port, out_dir, packed=True):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -332,17 +332,18 @@ def _seed_worker(rank, world, port, out_dir):
     draws = [seeding.draw(rs, n, k) for _ in range(b)]
     lo, hi = pdist.shard_bounds(n, rank, world)
     centers, indices = seeding.kmeans_plusplus_sharded(torch.from_numpy(Xc[lo:hi].copy()), lo, n, k, draws,
-                                                       ops=NumpySeedOps())
+                                                       ops=NumpySeedOps(), packed=packed)
     np.savez(os.path.join(out_dir, f"s{rank}.npz"), centers=centers.numpy(), indices=indices.numpy())
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_seeding_matches_oracle(world, tmp_path):
+@pytest.mark.parametrize("world,packed", [(1, True), (2, True), (3, True), (2, False), (3, False)])
+def test_sharded_seeding_matches_oracle(world, packed, tmp_path):
     """k-means++ over row-sharded points (ranks' cumulative-sum offsets, counted draws, exchanged candidate
-    rows, all-reduced potentials): every rank ends with the seeds sklearn's algorithm picks, restart by
-    restart, from the same RandomState stream."""
-    mp.spawn(_seed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rows, gathered potentials): every rank ends with the seeds sklearn's algorithm picks, restart by
+    restart, from the same RandomState stream -- with the two packed all-gathers per centre and with the
+    fetch-by-index exchange the packed form falls back to."""
+    mp.spawn(_seed_worker, args=(world, _free_port(), str(tmp_path), packed), nprocs=world, join=True)
     Xc = _seed_case()
     rs = np.random.RandomState(17)
     want = [O.kmeans_plusplus(Xc, 12, rs, pot="f64") for _ in range(3)]  # the sharded seeding sums in double

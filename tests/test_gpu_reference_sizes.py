@@ -66,6 +66,25 @@ def test_seeding_in_openblas_order_matches_oracle(n, d, k, b, gpu_device):
         assert np.array_equal(idx[r].cpu().numpy(), oi), (n, k, r)
 
 
+@pytest.mark.parametrize("n,d", [(73568, 96), (17970, 96), (5001, 7), (1000, 128), (513, 200), (511, 16), (1, 3)])
+def test_column_statistics_in_numpy_order(n, d, gpu_device):
+    """mtp_col_seqsum_f32 against oracle.c's restatement of np.add.reduce(X, axis=0) (itself checked against NumPy
+    in the CPU suite), and tolerance_and_mean against X.mean(axis=0) / sklearn's _tolerance: bit for bit."""
+    from pccs_accel import clustering
+    from pccs_accel import kernels as K
+    rs = np.random.RandomState(n + d)
+    X = (rs.randn(n, d) * 10.0 ** rs.uniform(-2, 2, size=(n, d))).astype(np.float32)
+    Xd = torch.from_numpy(X).to(gpu_device)
+    got = K.col_seqsum(Xd).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), O.col_seqsum(X).view(np.uint32))
+    mean = X.mean(axis=0)
+    got = K.col_seqsum(Xd, torch.from_numpy(mean).to(gpu_device)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), O.col_seqsum(X, mean).view(np.uint32))
+    tol_abs, mean32 = clustering.tolerance_and_mean(Xd, 1e-4)
+    assert np.array_equal(mean32.cpu().numpy().view(np.uint32), mean.view(np.uint32))
+    assert tol_abs == float(O.tolerance(X, 1e-4))
+
+
 def _g14_inputs(g):
     X = datagen.make_encodings(int(g["seed"]), int(g["n"]), int(g["d"]), int(g["k_true"]), int(g["spread"]),
                                int(g["noise"]))
@@ -89,13 +108,12 @@ def test_seeded_fit_at_reference_size(name, gpu_device):
     seeds_equal = [bool(np.array_equal(got_idx[r], g["kpp_indices"][r])) for r in range(20)]
     assert all(seeds_equal), f"{name}: restarts with sklearn's seeds: {sum(seeds_equal)}/20"
 
-    # (2) the deterministic variant: oracle Lloyd with double sums from those seeds, restart by restart
-    # (the product's column mean and tolerance come from double sums, DESIGN.md deviation (ii): the oracle is
-    # given the same centred points and tolerance, so that this block checks the Lloyd loop and nothing else)
+    # (2) the deterministic variant: oracle Lloyd with double sums from those seeds, restart by restart, on
+    # NumPy's centred points with sklearn's tolerance (the product's are the same bits, asserted first)
     tol = fit["tol_abs"]
-    assert np.isclose(tol, float(O.tolerance(X)), rtol=1e-5)
+    assert tol == float(O.tolerance(X))  # NumPy's float order for the column statistics: the same bits
     x_mean = fit["x_mean"].cpu().numpy()
-    assert np.allclose(x_mean, X.mean(axis=0), rtol=1e-4, atol=1e-7)
+    assert np.array_equal(x_mean.view(np.uint32), X.mean(axis=0).view(np.uint32))
     Xc = np.ascontiguousarray(X - x_mean)
     labels_gpu = [r["labels"].cpu().numpy() for r in restarts]
     for r in range(20):
