@@ -414,84 +414,123 @@ extern "C" int mtp_col_sqdev_f32(const float *X, int64_t n, int d, const double 
 // _mean, _var): a sum in another order moves the column means by an ulp, the centred points with them, and
 // a few points per 7e4 change cluster.  One chain of n dependent float additions per column: the kernel is
 // bound by the addition latency (~n x 6 clocks), not by memory.  A workgroup owns 16 columns; all 256
-// threads bring tiles of 512 rows x 16 columns to LDS (double buffered, the next tile's loads are in flight
-// while this one is walked), 16 lanes walk them.
+// threads bring tiles of 512 rows x 16 columns to LDS (column-major, double buffered, the next tile's loads are
+// in flight while this one is walked), 16 lanes walk them with 16-byte LDS reads.
 // SQ: the summand is (x - center[c])^2 formed in float like NumPy's x = arr - arrmean; x * x.
 // ------------------------------------------------------------------------------------------
-constexpr int SEQ_COLS = 16, SEQ_ROWS = 512;
+constexpr int SEQ_COLS = 16, SEQ_ROWS = 512, SEQ_PITCH = SEQ_ROWS + 4;  // LDS tile: [column][row], rows padded
 
-template <bool SQ>
+// VEC: d % 4 == 0, a thread loads 16 bytes (4 columns of one row) at a time; else one float.
+template <bool SQ, bool VEC>
 __global__ __launch_bounds__(256) void k_col_seqsum(const float *__restrict__ X, int64_t n, int d,
                                                     const float *__restrict__ center, float *out) {
-    __shared__ float tile[2][SEQ_ROWS * SEQ_COLS];
+    // three tile buffers: one being walked, one complete, one being filled; the global loads of a tile are
+    // issued two walks before the tile is needed (two register sets), so their latency stays off the chain
+    __shared__ __attribute__((aligned(16))) float tile[3][SEQ_COLS * SEQ_PITCH];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * SEQ_COLS;
-    const int lc = tid & (SEQ_COLS - 1), lr = tid >> 4;  // this thread loads column c0 + lc of rows lr, lr + 16, ...
-    const bool col_ok = c0 + lc < d;
-    constexpr int PER = SEQ_ROWS / 16;  // loads per thread and tile
-    float v[PER];
-    auto load = [&](int64_t r0) {
+    // VEC: columns c0 + 4 q .. + 3 of rows r, r + 64, ...;  scalar: column c0 + lc of rows lr, lr + 16, ...
+    const int q = tid & 3, vr = tid >> 2;
+    const int lc = tid & (SEQ_COLS - 1), lr = tid >> 4;
+    constexpr int PER = SEQ_ROWS * SEQ_COLS / 256;  // floats per thread and tile (32)
+    float mu[4] = {0.f, 0.f, 0.f, 0.f};
+    if (SQ) {
+        if (VEC) {
+            for (int e = 0; e < 4; ++e)
+                if (c0 + 4 * q + e < d) mu[e] = center[c0 + 4 * q + e];
+        } else if (c0 + lc < d) {
+            mu[0] = center[c0 + lc];
+        }
+    }
+    auto load = [&](int64_t r0, float(&v)[PER]) {
+        if (VEC) {
+#pragma unroll
+            for (int e = 0; e < PER / 4; ++e) {
+                const int64_t r = r0 + vr + 64 * e;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < n && c0 + 4 * q < d) w = *reinterpret_cast<const float4 *>(X + r * d + c0 + 4 * q);
+                v[4 * e] = w.x, v[4 * e + 1] = w.y, v[4 * e + 2] = w.z, v[4 * e + 3] = w.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const int64_t r = r0 + lr + 16 * e;
+                v[e] = (c0 + lc < d && r < n) ? X[r * d + c0 + lc] : 0.f;
+            }
+        }
+    };
+    // the summands are formed by the loading threads (all 256), so that the walk is additions only;
+    // rows past the end are not walked
+    auto store = [&](int buf, const float(&v)[PER]) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            const int64_t r = r0 + lr + 16 * e;
-            v[e] = (col_ok && r < n) ? X[r * d + c0 + lc] : 0.f;
+            float w = v[e];
+            if (SQ) {
+                const float x = w - mu[VEC ? (e & 3) : 0];
+                w = x * x;
+            }
+            if (VEC)
+                tile[buf][(4 * q + (e & 3)) * SEQ_PITCH + vr + 64 * (e >> 2)] = w;
+            else
+                tile[buf][lc * SEQ_PITCH + lr + 16 * e] = w;
         }
     };
-    auto store = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < PER; ++e) tile[buf][(lr + 16 * e) * SEQ_COLS + lc] = v[e];
-    };
-    const float mu = (SQ && col_ok) ? center[c0 + lc] : 0.f;
     float acc = 0.f;
-    load(0);
-    store(0);
-    __syncthreads();
-    int buf = 0;
-    for (int64_t r0 = 0; r0 < n; r0 += SEQ_ROWS) {
-        const bool more = r0 + SEQ_ROWS < n;
-        if (more) load(r0 + SEQ_ROWS);
-        if (tid < SEQ_COLS) {
-            const int rows = (int)((n - r0) < SEQ_ROWS ? (n - r0) : SEQ_ROWS);
-            const float *t = tile[buf] + tid;
-            int r = 0;
-            for (; r + 32 <= rows; r += 32) {
-                float w[32];
+    auto walk = [&](int buf, int64_t r0) {
+        if (tid >= SEQ_COLS) return;
+        const int rows = (int)((n - r0) < SEQ_ROWS ? (n - r0) : SEQ_ROWS);
+        const float *t = tile[buf] + tid * SEQ_PITCH;
+        int r = 0;
+        for (; r + 32 <= rows; r += 32) {
+            float4 w[8];
 #pragma unroll
-                for (int e = 0; e < 32; ++e) w[e] = t[(r + e) * SEQ_COLS];
+            for (int e = 0; e < 8; ++e) w[e] = *reinterpret_cast<const float4 *>(t + r + 4 * e);
 #pragma unroll
-                for (int e = 0; e < 32; ++e) {
-                    if (SQ) {
-                        const float x = w[e] - mu;
-                        acc = acc + x * x;
-                    } else {
-                        acc = acc + w[e];
-                    }
-                }
-            }
-            for (; r < rows; ++r) {
-                const float w = t[r * SEQ_COLS];
-                if (SQ) {
-                    const float x = w - mu;
-                    acc = acc + x * x;
-                } else {
-                    acc = acc + w;
-                }
+            for (int e = 0; e < 8; ++e) {
+                acc = acc + w[e].x;
+                acc = acc + w[e].y;
+                acc = acc + w[e].z;
+                acc = acc + w[e].w;
             }
         }
-        if (more) store(buf ^ 1);
+        for (; r < rows; ++r) acc = acc + t[r];
+    };
+    const int64_t n_tiles = (n + SEQ_ROWS - 1) / SEQ_ROWS;
+    float va[PER], vb[PER];
+    // tiles 0 and 1 into LDS, tile 2 into va
+    load(0, va);
+    store(0, va);
+    load(SEQ_ROWS, va);
+    store(1, va);
+    load(2 * (int64_t)SEQ_ROWS, va);
+    __syncthreads();
+    // iteration t: walk tile t; tile t + 2 (loaded during iteration t - 1) goes to LDS; tile t + 3 is requested
+    for (int64_t t = 0; t < n_tiles; t += 2) {
+        store((int)((t + 2) % 3), va);
+        load((t + 3) * SEQ_ROWS, vb);
+        walk((int)(t % 3), t * SEQ_ROWS);
         __syncthreads();
-        buf ^= 1;
+        if (t + 1 >= n_tiles) break;
+        store((int)((t + 3) % 3), vb);
+        load((t + 4) * SEQ_ROWS, va);
+        walk((int)((t + 1) % 3), (t + 1) * SEQ_ROWS);
+        __syncthreads();
     }
-    if (tid < SEQ_COLS && col_ok) out[c0 + tid] = acc;
+    if (tid < SEQ_COLS && c0 + tid < d) out[c0 + tid] = acc;
 }
 
 extern "C" int mtp_col_seqsum_f32(const float *X, int64_t n, int d, const float *center, float *out, void *stream) {
     MTP_REQUIRE(X && out && n >= 0 && d >= 1, "mtp_col_seqsum: bad arguments");
-    const unsigned blocks = (unsigned)((d + SEQ_COLS - 1) / SEQ_COLS);
-    if (center != nullptr)
-        hipLaunchKernelGGL(k_col_seqsum<true>, dim3(blocks), dim3(256), 0, mtp_stream(stream), X, n, d, center, out);
-    else
-        hipLaunchKernelGGL(k_col_seqsum<false>, dim3(blocks), dim3(256), 0, mtp_stream(stream), X, n, d, center, out);
+    const dim3 grid((unsigned)((d + SEQ_COLS - 1) / SEQ_COLS)), block(256);
+    hipStream_t s = mtp_stream(stream);
+    const bool vec = d % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    if (center != nullptr) {
+        if (vec) hipLaunchKernelGGL((k_col_seqsum<true, true>), grid, block, 0, s, X, n, d, center, out);
+        else hipLaunchKernelGGL((k_col_seqsum<true, false>), grid, block, 0, s, X, n, d, center, out);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_col_seqsum<false, true>), grid, block, 0, s, X, n, d, center, out);
+        else hipLaunchKernelGGL((k_col_seqsum<false, false>), grid, block, 0, s, X, n, d, center, out);
+    }
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
