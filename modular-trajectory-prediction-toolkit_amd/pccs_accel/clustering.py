@@ -70,9 +70,13 @@ def tolerance_and_mean(X, tol, order="numpy"):
 
 
 def is_same_clustering(l1, l2, k):
-    """sklearn cluster/_k_means_common.pyx:314-328: l1 -> l2 is a function (device check)."""
-    pairs = l1.to(torch.int64) * k + l2.to(torch.int64)
-    return torch.unique(pairs).numel() == torch.unique(l1).numel()
+    """sklearn cluster/_k_means_common.pyx:314-328: l1 -> l2 is a function (device check).  Every label of l1
+    remembers the l2 label of ONE of its points (which one does not matter); the mapping is a function iff every
+    point agrees with what its label remembers.  Two elementwise launches and one host read."""
+    i1 = l1.to(torch.int64)
+    mapping = torch.full((int(k),), -1, dtype=l2.dtype, device=l1.device)
+    mapping[i1] = l2
+    return bool((mapping[i1] == l2).all())
 
 
 def restart_batch(n, d, k, n_init):

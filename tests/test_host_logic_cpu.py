@@ -127,3 +127,20 @@ def test_seeding_draw_order_matches_sklearn_stream():
             for c in range(u.shape[0]):
                 assert np.array_equal(u[c], rs2.uniform(size=u.shape[1]))
         assert rs1.randint(1 << 30) == rs2.randint(1 << 30)   # both streams are at the same position
+
+
+def test_same_clustering_rule_matches_sklearns_loop():
+    """clustering.is_same_clustering (two elementwise launches on the device) against the dict walk of
+    sklearn cluster/_k_means_common.pyx:314-328 -- one-directional: l1 -> l2 must be a function."""
+    from pccs_accel.clustering import is_same_clustering
+    rs = np.random.RandomState(0)
+    for _ in range(300):
+        k, n = rs.randint(1, 6), rs.randint(0, 12)
+        l1, l2 = rs.randint(0, k, n).astype(np.int32), rs.randint(0, k, n).astype(np.int32)
+        mapping, want = {}, True
+        for a, b in zip(l1, l2):
+            if mapping.setdefault(a, b) != b:
+                want = False
+        assert is_same_clustering(torch.from_numpy(l1), torch.from_numpy(l2), k) == want
+    assert is_same_clustering(torch.tensor([0, 1, 2, 3]), torch.tensor([0, 0, 1, 1]), 4)
+    assert not is_same_clustering(torch.tensor([0, 0, 1, 1]), torch.tensor([0, 1, 2, 3]), 4)
