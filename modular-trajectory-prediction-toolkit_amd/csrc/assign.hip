@@ -99,12 +99,13 @@ int mtp_launch_stage_centers(const float *C, int k, int d, float *staged, float 
     return MTP_OK;
 }
 
-template <int D>
-static int launch_assign_mfma(const float *X, int64_t n, const float *staged, int k, int32_t *labels,
-                              double *n_changed, const int32_t *state, hipStream_t s, MtpBatchStride bs) {
+// One launch of the MFMA E-step with WPB waves (32 points each) per workgroup.
+template <int D, int WPB>
+static int launch_assign_mfma_wpb(const float *X, int64_t n, const float *staged, int k, int32_t *labels,
+                                  double *n_changed, const int32_t *state, hipStream_t s, MtpBatchStride bs) {
     // 8 waves x 32 points per workgroup, 2 workgroups (4 waves/SIMD) per CU: measured 4 % faster
     // than 4 waves x 64 points at 2 waves/SIMD (tools/assign_tune.hip, N=10M K=1024 D=128)
-    constexpr int PT = 1, CTW = 2, WPB = 8, WPS = 4;
+    constexpr int PT = 1, CTW = 2, WPS = 4;
     const size_t lds = 2 * (size_t)CTW * mtp_tile_floats(D) * sizeof(float);
     MTP_SET_MAX_LDS_ONCE((&k_assign_mfma<D, PT, CTW, WPB, WPS, true>), lds);
     const int64_t pts_per_block = WPB * 32 * PT;
@@ -114,6 +115,57 @@ static int launch_assign_mfma(const float *X, int64_t n, const float *staged, in
                        staged, (k + 31) / 32, labels, n_changed, state, bs);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
+}
+
+static int device_cu_count(int *cus) {
+    static std::atomic<int> cached[MTP_MAX_DEVICES];
+    int dev = 0;
+    MTP_HIP(hipGetDevice(&dev));
+    const bool track = dev >= 0 && dev < MTP_MAX_DEVICES;
+    int c = track ? cached[dev].load(std::memory_order_acquire) : 0;
+    if (c == 0) {
+        MTP_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
+        if (c < 1) c = 1;
+        if (track) cached[dev].store(c, std::memory_order_release);
+    }
+    *cus = c;
+    return MTP_OK;
+}
+
+// The chip holds 2 workgroups of 8 waves per CU (68 KB of LDS, 128 VGPRs each): one ROUND = 2 x CUs workgroups.
+// Workgroups of equal cost run in lockstep, and the hardware spreads a last, partial round of up to CUs
+// workgroups one per CU but puts anything beyond that two per CU on some CUs: the launch time moves in steps
+// of half a round (tools/assign_sweep.sh), and N = 1.25 M points (9.54 rounds on 256 CUs) pays for 10.0.
+// So a single run is issued as two launches on the stream: the whole rounds with the 8-wave workgroups, then
+// the remaining points with workgroups of w = ceil(remaining waves / CUs) waves, rounded up to 4, 8, 12 or 16
+// (16 = a whole CU's wave slots at this register budget) -- at most one workgroup per CU, so the tail costs
+// w / 16 of a round instead of 1/2 or 1.  At N = 1.25 M: 36 + 3 tile-times per SIMD instead of 36 + 4
+// (2.41 against 2.47 ms; the optimum for 32-point wave tiles, 38.15 rounded up).  The labels do not depend on the split
+// (every point is scored against every centroid by the same instruction sequence).
+// Batched restarts (blockIdx.y) keep the single launch: their tail is restart-major and small against 20 x N.
+template <int D>
+static int launch_assign_mfma(const float *X, int64_t n, const float *staged, int k, int32_t *labels,
+                              double *n_changed, const int32_t *state, hipStream_t s, MtpBatchStride bs) {
+    if (bs.batch != 1) return launch_assign_mfma_wpb<D, 8>(X, n, staged, k, labels, n_changed, state, s, bs);
+    int cus = 0;
+    const int rc = device_cu_count(&cus);
+    if (rc != MTP_OK) return rc;
+    const int64_t per_round = (int64_t)2 * cus * 256;  // points
+    const int64_t n_main = n / per_round * per_round;
+    if (n_main > 0) {
+        const int r = launch_assign_mfma_wpb<D, 8>(X, n_main, staged, k, labels, n_changed, state, s, bs);
+        if (r != MTP_OK) return r;
+    }
+    const int64_t n_tail = n - n_main;
+    if (n_tail == 0) return MTP_OK;
+    const int64_t w = ((n_tail + 31) / 32 + cus - 1) / cus;  // waves per CU, 1 ... 16
+    const float *Xt = X + n_main * D;
+    int32_t *lt = labels + n_main;
+    // whole waves per SIMD: a workgroup's waves go round the CU's 4 SIMDs, and 10 waves take as long as 12
+    if (w <= 4) return launch_assign_mfma_wpb<D, 4>(Xt, n_tail, staged, k, lt, n_changed, state, s, bs);
+    if (w <= 8) return launch_assign_mfma_wpb<D, 8>(Xt, n_tail, staged, k, lt, n_changed, state, s, bs);
+    if (w <= 12) return launch_assign_mfma_wpb<D, 12>(Xt, n_tail, staged, k, lt, n_changed, state, s, bs);
+    return launch_assign_mfma_wpb<D, 16>(Xt, n_tail, staged, k, lt, n_changed, state, s, bs);
 }
 
 int mtp_launch_assign(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2, int k,

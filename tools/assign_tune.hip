@@ -27,6 +27,16 @@ __global__ void k_fill(float *p, size_t n, unsigned seed) {
 
 static MtpBatchStride g_bs = mtp_no_batch();  // restarts: same points, own centroid image and labels
 
+// filter: substrings separated by '|'
+static bool name_matches(const char *name, const char *filter) {
+    char buf[256];
+    strncpy(buf, filter, sizeof(buf) - 1);
+    buf[sizeof(buf) - 1] = 0;
+    for (char *tok = strtok(buf, "|"); tok != nullptr; tok = strtok(nullptr, "|"))
+        if (strstr(name, tok)) return true;
+    return false;
+}
+
 struct Variant {
     const char *name;
     void (*launch)(const float *, int64_t, const float *, int, int32_t *, hipStream_t);
@@ -61,6 +71,31 @@ void launch_pipe(const float *X, int64_t n, const float *staged, int k, int32_t 
     hipLaunchKernelGGL((k_assign_mfma_pipe<D, WPB, WPS, LG>), dim3((unsigned)((n + ppb - 1) / ppb), g_bs.batch), dim3(64 * WPB), lds, s, X, n,
                        staged, mtp_n_tiles(k), labels, nullptr, nullptr, g_bs);
     CK(hipGetLastError());
+}
+
+// The plain grid in two launches: whole rounds of 512 workgroups, then the rest with workgroups of WT waves,
+// WT chosen so that at most one workgroup per CU is needed (the hardware spreads <= 256 workgroups one per CU).
+template <int D, int WT>
+void launch_tail(const float *X, int64_t n, const float *staged, int k, int32_t *labels, hipStream_t s) {
+    launch_v<D, 1, 2, WT, 4, true>(X, n, staged, k, labels, s);
+}
+template <int D>
+void launch_split(const float *X, int64_t n, const float *staged, int k, int32_t *labels, hipStream_t s) {
+    const int cus = 256, slots = 2 * cus;
+    const int64_t blocks = (n + 255) / 256;
+    const int64_t full = blocks / slots * slots;
+    const int64_t n_main = full * 256 < n ? full * 256 : n;
+    const int64_t n_tail = n - n_main;
+    if (n_main > 0) launch_v<D, 1, 2, 8, 4, true>(X, n_main, staged, k, labels, s);
+    if (n_tail <= 0) return;
+    const int64_t waves = (n_tail + 31) / 32;
+    const int w = (int)((waves + cus - 1) / cus);
+    const float *Xt = X + n_main * D;
+    int32_t *lt = labels + n_main;
+    if (w <= 4) launch_tail<D, 4>(Xt, n_tail, staged, k, lt, s);
+    else if (w <= 8) launch_tail<D, 8>(Xt, n_tail, staged, k, lt, s);
+    else if (w <= 12) launch_tail<D, 12>(Xt, n_tail, staged, k, lt, s);
+    else launch_tail<D, 16>(Xt, n_tail, staged, k, lt, s);
 }
 
 static unsigned *g_tickets = nullptr;
@@ -115,7 +150,8 @@ int run(int64_t n, int k, const char *filter, int batch) {
     CK(hipDeviceSynchronize());
 
     std::vector<Variant> vs = {
-        {"PT1 CTW2 WPB8 WPS4 (product)", launch_v<D, 1, 2, 8, 4, true>, true},
+        {"PT1 CTW2 WPB8 WPS4 (one launch)", launch_v<D, 1, 2, 8, 4, true>, true},
+        {"SPLIT rounds + tail (product)", launch_split<D>, true},
         {"QUEUE small 0", launch_queue<D, 4, 0>, true},
         {"QUEUE small 1/wg", launch_queue<D, 4, 1>, true},
         {"QUEUE small 2/wg", launch_queue<D, 4, 2>, true},
@@ -134,7 +170,7 @@ int run(int64_t n, int k, const char *filter, int batch) {
     if (filter != nullptr) {  // keep the variants whose name contains it (the product variant always stays)
         std::vector<Variant> keep;
         for (size_t v = 0; v < vs.size(); ++v)
-            if (v == 0 || strstr(vs[v].name, filter)) keep.push_back(vs[v]);
+            if (v == 0 || name_matches(vs[v].name, filter)) keep.push_back(vs[v]);
         vs = keep;
     }
     hipEvent_t e0, e1;
