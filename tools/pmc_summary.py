@@ -64,6 +64,23 @@ def main():
                 # they are not the kernel's work and are left out of the averages
                 live = [x for x in v if x > 0.02 * max(v)] if max(v) > 0 else v
                 e[c] = {"launches": len(live), "noop_launches_dropped": len(v) - len(live), "avg": sum(live) / len(live)}
+    # The E-step of a single run is two launches per iteration since round 2 (whole rounds of 8-wave workgroups, then
+    # the remaining points with wider ones: another instantiation, or the same one on a few workgroups): per
+    # iteration = the mean of the big launches + the small ones' total spread over them.
+    estep = {}
+    for kind in ("fetch", "write"):
+        files = glob.glob(os.path.join(out, f"{tag}_pmc_{kind}", "**", "*_counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        per_d = collections.defaultdict(list)
+        for k, cs in counters(files[0]).items():
+            if k.startswith("k_assign_mfma<"):
+                for c, v in cs.items():
+                    per_d[(k.split(",")[0], c)] += v
+        for (kd, c), v in per_d.items():
+            big = [x for x in v if x > 0.5 * max(v)]
+            small = [x for x in v if 1e-4 * max(v) < x <= 0.5 * max(v)]
+            estep.setdefault(kd, {})[c] = sum(big) / len(big) + sum(small) / len(big)
     traffic = {}
     for k, e in summary.items():
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
@@ -73,6 +90,12 @@ def main():
             # MFMA busy cycles are summed over 1024 SIMDs, GRBM_GUI_ACTIVE over 8 XCDs
             e["mfma_busy_frac"] = (e["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / 1024) / (e["GRBM_GUI_ACTIVE"]["avg"] / 8)
     bench = json.load(open(os.path.join(out, f"{tag}_pmc_fetch.json")))
+    kd = "k_assign_mfma<%d" % bench["config"]["d"]
+    if kd in estep and "FETCH_SIZE" in estep[kd] and "WRITE_SIZE" in estep[kd]:
+        traffic["k_assign_mfma"] = 2 * estep[kd]["FETCH_SIZE"] * 1024 + estep[kd]["WRITE_SIZE"] * 1024
+        summary[kd + ", ...> per iteration (all launches)"] = {"FETCH_SIZE": estep[kd]["FETCH_SIZE"],
+                                                              "WRITE_SIZE": estep[kd]["WRITE_SIZE"],
+                                                              "hbm_bytes_per_launch": traffic["k_assign_mfma"]}
     json.dump({"source": f"gpurun_out/{tag}_pmc_*", "bench_config": bench["config"], "kernels": summary},
               open(os.path.join(prof, f"{rnd}_pmc.json"), "w"), indent=1)
     json.dump({"round": rnd, "n": bench["config"]["n"], "d": bench["config"]["d"], "k": bench["config"]["k"],
