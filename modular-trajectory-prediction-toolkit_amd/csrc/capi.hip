@@ -688,11 +688,11 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
         const int n_iter = hflags[(size_t)b * MTP_FLAG_WORDS + MTP_FLAG_N_ITER];
         float *c0 = C_inout + (size_t)b * k * d;
         if (n_iter & 1) MTP_HIP(hipMemcpyAsync(c0, at(w.c_alt, b), (size_t)k * d * 4, hipMemcpyDeviceToDevice, s));
-        if (inertia_out != nullptr) {
-            rc = mtp_launch_inertia(X, n, d, c0, labels_out + (size_t)b * n, inertia_out + b, nullptr, s);
-            if (rc != MTP_OK) return rc;
-        }
         if (n_iter_out != nullptr) n_iter_out[b] = n_iter;
+    }
+    if (inertia_out != nullptr) {  // all restarts in one launch
+        rc = mtp_launch_inertia_batched(X, n, d, C_inout, labels_out, inertia_out, nullptr, batch, (size_t)k * d, (size_t)n, s);
+        if (rc != MTP_OK) return rc;
     }
     MTP_HIP(hipStreamSynchronize(s));
     return MTP_OK;

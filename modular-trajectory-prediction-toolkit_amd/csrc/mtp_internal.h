@@ -105,6 +105,8 @@ int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d
                      hipStream_t s, MtpBatchStride bs = mtp_no_batch(), int flag_parity = 0);
 int mtp_launch_inertia(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
                        float *per_point, hipStream_t s);
+int mtp_launch_inertia_batched(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
+                               float *per_point, int batch, size_t c_stride, size_t lab_stride, hipStream_t s);
 
 // ||row||^2 in NumPy einsum("ij,ij->i") float order (see oracle.c orc_row_sqnorm_f32): four lane
 // accumulators, product rounded then added, blocks of 16 consumed vector 3,2,1,0, tail vectors in

@@ -277,7 +277,11 @@ extern "C" int mtp_cluster_means_f32(const double *sums, const double *counts, i
 template <int LPR>
 __global__ __launch_bounds__(256) void k_inertia(const float *__restrict__ X, int64_t n, int d,
                                                  const float *__restrict__ C, const int32_t *__restrict__ labels,
-                                                 double *inertia, float *per_point) {
+                                                 double *inertia, float *per_point, size_t c_stride, size_t lab_stride) {
+    // restarts along blockIdx.y: own centres, labels and sum (per_point only with one restart)
+    C += blockIdx.y * c_stride;
+    labels += blockIdx.y * lab_stride;
+    if (inertia != nullptr) inertia += blockIdx.y;
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sub = lane / LPR, c0 = lane % LPR;
     const int dq = d / 4;
@@ -316,7 +320,10 @@ __global__ __launch_bounds__(256) void k_inertia(const float *__restrict__ X, in
 __global__ __launch_bounds__(256) void k_inertia_scalar(const float *__restrict__ X, int64_t n, int d,
                                                         const float *__restrict__ C,
                                                         const int32_t *__restrict__ labels, double *inertia,
-                                                        float *per_point) {
+                                                        float *per_point, size_t c_stride, size_t lab_stride) {
+    C += blockIdx.y * c_stride;
+    labels += blockIdx.y * lab_stride;
+    if (inertia != nullptr) inertia += blockIdx.y;
     double local = 0.0;
     for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
         const float v = euclid_sq_sklearn(X + row * d, C + (size_t)labels[row] * d, d);
@@ -331,23 +338,31 @@ __global__ __launch_bounds__(256) void k_inertia_scalar(const float *__restrict_
     if (threadIdx.x == 0) atomicAdd(inertia, part[0] + part[1] + part[2] + part[3]);
 }
 
-int mtp_launch_inertia(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
-                       float *per_point, hipStream_t s) {
-    if (n == 0) return MTP_OK;
+// batch > 1: restart b uses C + b * c_stride, labels + b * lab_stride, inertia[b] (per_point must be NULL)
+int mtp_launch_inertia_batched(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
+                               float *per_point, int batch, size_t c_stride, size_t lab_stride, hipStream_t s) {
+    if (n == 0 || batch == 0) return MTP_OK;
+    MTP_REQUIRE(batch == 1 || per_point == nullptr, "mtp_inertia: per-point distances only for one restart");
+    MTP_REQUIRE(batch >= 1 && batch <= 65535, "mtp_inertia: batch must be in [1, 65535]");
     int64_t blocks = (n + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    const dim3 grid((unsigned)blocks), block(256);
+    const dim3 grid((unsigned)blocks, (unsigned)batch), block(256);
     if (d % 4 != 0) {
-        hipLaunchKernelGGL(k_inertia_scalar, grid, block, 0, s, X, n, d, C, labels, inertia, per_point);
+        hipLaunchKernelGGL(k_inertia_scalar, grid, block, 0, s, X, n, d, C, labels, inertia, per_point, c_stride, lab_stride);
     } else if (d / 4 <= 8) {
-        hipLaunchKernelGGL(k_inertia<8>, grid, block, 0, s, X, n, d, C, labels, inertia, per_point);
+        hipLaunchKernelGGL(k_inertia<8>, grid, block, 0, s, X, n, d, C, labels, inertia, per_point, c_stride, lab_stride);
     } else if (d / 4 <= 16) {
-        hipLaunchKernelGGL(k_inertia<16>, grid, block, 0, s, X, n, d, C, labels, inertia, per_point);
+        hipLaunchKernelGGL(k_inertia<16>, grid, block, 0, s, X, n, d, C, labels, inertia, per_point, c_stride, lab_stride);
     } else {
-        hipLaunchKernelGGL(k_inertia<32>, grid, block, 0, s, X, n, d, C, labels, inertia, per_point);
+        hipLaunchKernelGGL(k_inertia<32>, grid, block, 0, s, X, n, d, C, labels, inertia, per_point, c_stride, lab_stride);
     }
     MTP_LAUNCH_CHECK();
     return MTP_OK;
+}
+
+int mtp_launch_inertia(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
+                       float *per_point, hipStream_t s) {
+    return mtp_launch_inertia_batched(X, n, d, C, labels, inertia, per_point, 1, 0, 0, s);
 }
 
 // ------------------------------------------------------------------------------------------
