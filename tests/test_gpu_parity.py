@@ -69,6 +69,23 @@ def test_assign_ragged_shapes(n, d, k, gpu_device):
     assert int(n_changed.item()) == 0
 
 
+@pytest.mark.parametrize("delta", [-33, 0, 1, 257, 2199 * 32 - 7, 3000 * 32])
+def test_assign_split_launch_boundaries(delta, gpu_device):
+    """A single E-step is issued as two launches (whole rounds of 2 x CUs workgroups of 256 points, then the
+    remaining points with workgroups of 4 / 8 / 12 / 16 waves): point counts just below, at and above whole rounds,
+    and remainders that select every tail workgroup size, against the oracle; n_changed over both launches."""
+    from pccs_accel import kernels as K
+    per_round = 2 * torch.cuda.get_device_properties(gpu_device).multi_processor_count * 256
+    n, d, k = per_round + delta, 64, 40
+    X = datagen.make_encodings(500 + (delta % 97), n, d, 20, 1500, 700)
+    C = X[datagen.make_init_indices(9, n, k)].copy()
+    prev = torch.full((n,), -1, dtype=torch.int32, device=gpu_device)
+    n_changed = torch.zeros(1, dtype=torch.float64, device=gpu_device)
+    labels = K.assign(dev(X, gpu_device), dev(C, gpu_device), prev, n_changed).cpu().numpy()
+    assert np.array_equal(labels, O.assign(X, C, backend="chain"))
+    assert int(n_changed.item()) == n
+
+
 def test_assign_exact_ties_take_lowest_index(gpu_device):
     """Duplicate centroids: strict '<' keeps the first (sklearn _k_means_lloyd.pyx:205-213)."""
     from pccs_accel import kernels as K
