@@ -80,6 +80,11 @@ int mtp_sub_rowvec_f32(float *X, int64_t n, int d, const float *vec, void *strea
  * :1478-1481 do, bit for bit, so that the centred points and the tolerance are the reference's.
  * out is overwritten ([d] floats). */
 int mtp_col_seqsum_f32(const float *X, int64_t n, int d, const float *center, float *out, void *stream);
+/* The same with the chains started from init[d] instead of zero (init may equal out): rows [lo, lo + n) of a
+ * row-sharded array continue the sums of the rows before them, rank after rank, so that the sharded fit
+ * (pccs_accel.dist.kmeans_fit_sharded) centres the points with NumPy's mean too. */
+int mtp_col_seqsum_carry_f32(const float *X, int64_t n, int d, const float *center, const float *init, float *out,
+                             void *stream);
 
 /* E-step: labels[i] = argmin_j (||c_j||^2 - 2 x_i.c_j), strict '<', lowest index wins.
  * Replaces sklearn cluster/_k_means_lloyd.pyx:168-213 (_update_chunk_dense, E part) -- the

@@ -438,7 +438,8 @@ constexpr int SEQ_COLS = 16, SEQ_ROWS = 512, SEQ_PITCH = SEQ_ROWS + 4;  // LDS t
 // VEC: d % 4 == 0, a thread loads 16 bytes (4 columns of one row) at a time; else one float.
 template <bool SQ, bool VEC>
 __global__ __launch_bounds__(256) void k_col_seqsum(const float *__restrict__ X, int64_t n, int d,
-                                                    const float *__restrict__ center, float *out) {
+                                                    const float *__restrict__ center, const float *__restrict__ init,
+                                                    float *out) {
     // three tile buffers: one being walked, one complete, one being filled; the global loads of a tile are
     // issued two walks before the tile is needed (two register sets), so their latency stays off the chain
     __shared__ __attribute__((aligned(16))) float tile[3][SEQ_COLS * SEQ_PITCH];
@@ -490,7 +491,8 @@ __global__ __launch_bounds__(256) void k_col_seqsum(const float *__restrict__ X,
                 tile[buf][lc * SEQ_PITCH + lr + 16 * e] = w;
         }
     };
-    float acc = 0.f;
+    // init: the chain continues from another block of rows (row-sharded points: the rank before this one)
+    float acc = (init != nullptr && tid < SEQ_COLS && c0 + tid < d) ? init[c0 + tid] : 0.f;
     auto walk = [&](int buf, int64_t r0) {
         if (tid >= SEQ_COLS) return;
         const int rows = (int)((n - r0) < SEQ_ROWS ? (n - r0) : SEQ_ROWS);
@@ -534,20 +536,25 @@ __global__ __launch_bounds__(256) void k_col_seqsum(const float *__restrict__ X,
     if (tid < SEQ_COLS && c0 + tid < d) out[c0 + tid] = acc;
 }
 
-extern "C" int mtp_col_seqsum_f32(const float *X, int64_t n, int d, const float *center, float *out, void *stream) {
-    MTP_REQUIRE(X && out && n >= 0 && d >= 1, "mtp_col_seqsum: bad arguments");
+extern "C" int mtp_col_seqsum_carry_f32(const float *X, int64_t n, int d, const float *center, const float *init,
+                                        float *out, void *stream) {
+    MTP_REQUIRE((X || n == 0) && out && n >= 0 && d >= 1, "mtp_col_seqsum: bad arguments");
     const dim3 grid((unsigned)((d + SEQ_COLS - 1) / SEQ_COLS)), block(256);
     hipStream_t s = mtp_stream(stream);
     const bool vec = d % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     if (center != nullptr) {
-        if (vec) hipLaunchKernelGGL((k_col_seqsum<true, true>), grid, block, 0, s, X, n, d, center, out);
-        else hipLaunchKernelGGL((k_col_seqsum<true, false>), grid, block, 0, s, X, n, d, center, out);
+        if (vec) hipLaunchKernelGGL((k_col_seqsum<true, true>), grid, block, 0, s, X, n, d, center, init, out);
+        else hipLaunchKernelGGL((k_col_seqsum<true, false>), grid, block, 0, s, X, n, d, center, init, out);
     } else {
-        if (vec) hipLaunchKernelGGL((k_col_seqsum<false, true>), grid, block, 0, s, X, n, d, center, out);
-        else hipLaunchKernelGGL((k_col_seqsum<false, false>), grid, block, 0, s, X, n, d, center, out);
+        if (vec) hipLaunchKernelGGL((k_col_seqsum<false, true>), grid, block, 0, s, X, n, d, center, init, out);
+        else hipLaunchKernelGGL((k_col_seqsum<false, false>), grid, block, 0, s, X, n, d, center, init, out);
     }
     MTP_LAUNCH_CHECK();
     return MTP_OK;
+}
+
+extern "C" int mtp_col_seqsum_f32(const float *X, int64_t n, int d, const float *center, float *out, void *stream) {
+    return mtp_col_seqsum_carry_f32(X, n, d, center, nullptr, out, stream);
 }
 
 __global__ __launch_bounds__(256) void k_sub_rowvec(float *X, int64_t total, int d, const float *__restrict__ vec) {

@@ -27,6 +27,7 @@ SIGNATURES = {
     "mtp_col_sums_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "mtp_col_sqdev_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "mtp_col_seqsum_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "mtp_col_seqsum_carry_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "mtp_sub_rowvec_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "mtp_assign_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mtp_assign_noalloc_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp]),

@@ -52,6 +52,18 @@ def all_reduce_sum(t, group=None):
     return t
 
 
+def broadcast_from(t, src_rank, group=None):
+    """t of group rank ``src_rank`` on every rank (in place)."""
+    src = dist.get_global_rank(group, src_rank) if group is not None else src_rank
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
 def all_gather_cat(t, world_size, group=None):
     """cat of every rank's ``t`` (same shape on all ranks) along dim 0, on t's device."""
     src = t.cpu() if (t.is_cuda and _host_staged(group)) else t
@@ -414,7 +426,7 @@ def is_same_clustering_sharded(l1, l2, k, collective, group=None):
 
 def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_iter=300, check_every=1, group=None,
                        force_collectives=False, lagged_steps=0, n_clusters=None, n_init=20, random_state=None,
-                       lloyd_ops=None, seed_ops=None, stats=None, comm=None):
+                       lloyd_ops=None, seed_ops=None, stats=None, comm=None, stats_order=None, seqsum=None):
     """sklearn ``KMeans.fit`` over row-sharded, un-centred points (one process per GPU): global mean /
     tolerance by all-reduce of column sums, then
 
@@ -424,6 +436,11 @@ def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_it
         sklearn's rule (cluster/_kmeans.py:1525-1532).  ``random_state`` must denote the SAME stream on every
         rank: an int, or None with ``np.random.seed(s)`` called identically in every process.
 
+    ``stats_order``: "numpy" (default with the HIP kernels) -- the column sums behind ``X.mean(axis=0)`` and sklearn's
+    tolerance are float32 chains over ALL rows in row order, as NumPy forms them: rank r continues the chains where
+    rank r - 1 stopped (``mtp_col_seqsum_carry_f32``, one small broadcast per rank and pass), so the centred points and
+    the tolerance are those of the one-GPU fit and of sklearn, bit for bit; "f64": double sums, one all-reduce each
+    (default when the ``stats`` test hooks are given).  ``seqsum``: test hook for the "numpy" order.
     ``comm``: an ``RcclComm``; the Lloyd runs then go through ``mtp_lloyd_sharded_f32`` (loop and all-reduce inside
     the library) instead of the step-level driver ``ShardedLloyd``.
     Returns dict(labels (local), centers, inertia, n_iter, tol_abs).  ``lloyd_ops`` / ``seed_ops`` / ``stats``
@@ -434,17 +451,42 @@ def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_it
     if stats is None:
         from . import kernels as K
         col_sums, col_sqdev, sub_rowvec_ = K.col_sums, K.col_sqdev, K.sub_rowvec_
+        if seqsum is None:
+            seqsum = K.col_seqsum
     else:
         col_sums, col_sqdev, sub_rowvec_ = stats
-    col_sum = col_sums(X_local)
-    if collective:
-        all_reduce_sum(col_sum, group)
-    mean64 = col_sum / n_total
-    sqdev = col_sqdev(X_local, mean64)
-    if collective:
-        all_reduce_sum(sqdev, group)
-    tol_abs = float((sqdev / n_total).mean().item()) * tol if tol != 0 else 0.0
-    mean32 = mean64.to(torch.float32)
+    if stats_order is None:
+        stats_order = "numpy" if (stats is None or seqsum is not None) else "f64"
+    if stats_order == "numpy":
+        def chain(center):
+            # the ranks take turns in rank order; everyone ends with the sums over all rows
+            acc = torch.zeros(X_local.shape[1], dtype=torch.float32, device=X_local.device)
+            for r in range(ws if collective else 1):
+                if r == rank or not collective:
+                    acc = seqsum(X_local, center, acc)
+                if collective:
+                    broadcast_from(acc, r, group)
+            return acc
+        s = chain(None).cpu().numpy()
+        mean = np.true_divide(s, np.intp(n_total), out=s, casting="unsafe")  # numpy/_core/_methods.py _mean
+        mean32 = torch.from_numpy(mean).to(X_local.device)
+        tol_abs = 0.0
+        if tol != 0:
+            sq = chain(mean32).cpu().numpy()
+            var = np.true_divide(sq, np.intp(n_total), out=sq, casting="unsafe")  # _var
+            tol_abs = float(np.mean(var) * tol)
+    elif stats_order == "f64":
+        col_sum = col_sums(X_local)
+        if collective:
+            all_reduce_sum(col_sum, group)
+        mean64 = col_sum / n_total
+        sqdev = col_sqdev(X_local, mean64)
+        if collective:
+            all_reduce_sum(sqdev, group)
+        tol_abs = float((sqdev / n_total).mean().item()) * tol if tol != 0 else 0.0
+        mean32 = mean64.to(torch.float32)
+    else:
+        raise ValueError(f"stats_order must be 'numpy' or 'f64', got {stats_order!r}")
     Xc = X_local.clone()
     sub_rowvec_(Xc, mean32)
 

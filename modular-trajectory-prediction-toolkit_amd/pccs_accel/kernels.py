@@ -63,17 +63,19 @@ def col_sqdev(X, mean64, out=None):
     return out
 
 
-def col_seqsum(X, center=None):
+def col_seqsum(X, center=None, init=None):
     """float32 [d]: the columns of X (or of (X - center)**2, float arithmetic) summed row after row in
-    float32 -- NumPy's ``np.add.reduce(X, axis=0)`` order (``mtp_col_seqsum_f32``)."""
+    float32 -- NumPy's ``np.add.reduce(X, axis=0)`` order (``mtp_col_seqsum_carry_f32``).  ``init``: the sums
+    of the rows before these (row-sharded points), else zero."""
     _req(X, "X", torch.float32, 2)
-    if center is not None:
-        _req(center, "center", torch.float32, 1)
-        assert center.numel() == X.shape[1]
+    for name, t in (("center", center), ("init", init)):
+        if t is not None:
+            _req(t, name, torch.float32, 1)
+            assert t.numel() == X.shape[1]
     out = torch.empty(X.shape[1], dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
-        check(lib().mtp_col_seqsum_f32(ptr(X), X.shape[0], X.shape[1], ptr(center), ptr(out), stream_ptr()),
-              "mtp_col_seqsum_f32")
+        check(lib().mtp_col_seqsum_carry_f32(ptr(X), X.shape[0], X.shape[1], ptr(center), ptr(init), ptr(out),
+                                             stream_ptr()), "mtp_col_seqsum_carry_f32")
     return out
 
 

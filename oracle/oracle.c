@@ -366,8 +366,8 @@ float orc_sum_sdot(const float *x, int64_t n) {
  * with `center`, the summand of numpy/_core/_methods.py _var: x = arr - arrmean; x = x * x, in float.
  * X.mean(axis=0) and np.var(X, axis=0) divide these sums by n (sklearn cluster/_kmeans.py:279-287, :1478-1481).
  * Checked against NumPy itself in tests/test_oracle_golden.py. */
-void orc_col_seqsum_f32(const float *X, int64_t n, int d, const float *center, float *out) {
-    for (int c = 0; c < d; ++c) out[c] = 0.f;
+void orc_col_seqsum_f32(const float *X, int64_t n, int d, const float *center, const float *init, float *out) {
+    for (int c = 0; c < d; ++c) out[c] = init ? init[c] : 0.f; /* init: the sums of the rows before these */
     for (int64_t i = 0; i < n; ++i) {
         const float *x = X + i * d;
         if (center) {

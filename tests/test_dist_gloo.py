@@ -355,7 +355,7 @@ def test_sharded_seeding_matches_oracle(world, packed, tmp_path):
             assert np.array_equal(p["centers"][r], want[r][0])
 
 
-def _fit_worker(rank, world, port, out_dir):
+def _fit_worker(rank, world, port, out_dir, numpy_stats=False):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -365,10 +365,14 @@ def _fit_worker(rank, world, port, out_dir):
     lo, hi = pdist.shard_bounds(X.shape[0], rank, world)
     stats = (lambda A: A.double().sum(dim=0), lambda A, m: ((A.double() - m) ** 2).sum(dim=0),
              lambda A, v: A.sub_(v))
+    seqsum = None
+    if numpy_stats:  # the column statistics as float32 chains over all rows, carried from rank to rank
+        def seqsum(A, center, init):
+            return torch.from_numpy(O.col_seqsum(A.numpy(), None if center is None else center.numpy(), init.numpy()))
     fit = pdist.kmeans_fit_sharded(torch.from_numpy(X[lo:hi].copy()), X.shape[0], row_offset=lo, n_clusters=9, n_init=4,
-                                   random_state=5, lloyd_ops=NumpyOps(), seed_ops=NumpySeedOps(), stats=stats)
+                                   random_state=5, lloyd_ops=NumpyOps(), seed_ops=NumpySeedOps(), stats=stats, seqsum=seqsum)
     np.savez(os.path.join(out_dir, f"f{rank}.npz"), labels=fit["labels"].numpy(), centers=fit["centers"].numpy(),
-             inertia=fit["inertia"], n_iter=fit["n_iter"])
+             inertia=fit["inertia"], n_iter=fit["n_iter"], tol_abs=fit["tol_abs"])
     dist.destroy_process_group()
 
 
@@ -376,15 +380,18 @@ def _fit_case():
     return np.ascontiguousarray(datagen.make_encodings(41, 901, 16, 9, 1500, 900))
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_full_fit_matches_oracle(world, tmp_path):
+@pytest.mark.parametrize("world,numpy_stats", [(1, False), (2, False), (3, False), (1, True), (2, True), (3, True)])
+def test_sharded_full_fit_matches_oracle(world, numpy_stats, tmp_path):
     """KMeans(n_clusters, n_init=4, random_state=5).fit over sharded points: global mean / tolerance, sharded
     k-means++ for all restarts, ShardedLloyd per restart, sklearn's best-restart rule with the sharded
     same-clustering check -- the oracle's labels, iteration count and inertia."""
-    mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path), numpy_stats), nprocs=world, join=True)
     X = _fit_case()
     want = O.kmeans_fit(X, 9, n_init=4, random_state=5, pot="f64")
     parts = [np.load(tmp_path / f"f{r}.npz") for r in range(world)]
+    if numpy_stats:  # the chains carried over the ranks give NumPy's own tolerance, whatever the number of ranks
+        for p in parts:
+            assert float(p["tol_abs"]) == float(O.tolerance(X))
     labels = np.concatenate([p["labels"] for p in parts])
     assert np.array_equal(labels, want["labels"])
     for p in parts:

@@ -80,6 +80,11 @@ def test_column_statistics_in_numpy_order(n, d, gpu_device):
     mean = X.mean(axis=0)
     got = K.col_seqsum(Xd, torch.from_numpy(mean).to(gpu_device)).cpu().numpy()
     assert np.array_equal(got.view(np.uint32), O.col_seqsum(X, mean).view(np.uint32))
+    # the chains continued over two row blocks (what the ranks of a row-sharded fit do): same bits
+    a = n // 3
+    part = K.col_seqsum(Xd[:a].clone())
+    got = K.col_seqsum(Xd[a:].clone(), None, part).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), O.col_seqsum(X).view(np.uint32))
     tol_abs, mean32 = clustering.tolerance_and_mean(Xd, 1e-4)
     assert np.array_equal(mean32.cpu().numpy().view(np.uint32), mean.view(np.uint32))
     assert tol_abs == float(O.tolerance(X, 1e-4))
