@@ -261,6 +261,22 @@ int mtp_kmeans_plusplus_f32(const float *X, int64_t n, int d, int k, int l, int6
 int64_t mtp_blas_order_rowsums_workspace_bytes(int64_t n, int l);
 int mtp_blas_order_rowsums_f32(const float *rows, int l, int64_t n, float *out, void *ws, size_t ws_bytes,
                                void *stream);
+
+/* The same two orders for rows that are cut into consecutive pieces at multiples of 4096 points -- row-sharded
+ * points, one piece per rank (pccs_accel.seeding.kmeans_plusplus_sharded).  sgemv_t: a rank forms the 4096-point
+ * block sums of its piece and the sum of its n & 3 trailing points (only the last piece has any),
+ *   part [batch][l][nb + 1], nb = mtp_blas_order_blocks(n);
+ * the pieces' parts are gathered, laid side by side in rank order and added one after the other in float
+ * (mtp_blas_order_combine_f32: out[r] = sum over part[r][0 .. m), total_rows rows) -- the additions of
+ * `rows @ sample_weight` (sklearn cluster/_kmeans.py:252) in OpenBLAS' order, whatever the number of ranks.
+ * sdot (cluster/_kmeans.py:216): acc [batch][64] travels from rank to rank over the first n_total & -64 points
+ * (main_local of them on this rank, a multiple of 64); the rank holding the last point passes finish = 1 and the
+ * left_over = n_total - (n_total & -32 & -64) points that follow, and receives out [batch]. */
+int64_t mtp_blas_order_blocks(int64_t n);
+int mtp_blas_order_block_sums_f32(const float *rows, int l, int64_t n, int batch, float *part, void *stream);
+int mtp_blas_order_combine_f32(const float *part, int64_t m, int64_t total_rows, float *out, void *stream);
+int mtp_blas_order_sdot_carry_f32(const float *x, int64_t row_stride, int batch, int64_t main_local, int64_t left_over,
+                                  float *acc, int finish, float *out, void *stream);
 /* The same for `batch` restarts sharing every launch: center_ids [batch] int64 (DEVICE), u [batch, k-1, l],
  * indices_out [batch, k], centers_out [batch, k, d]; ws: mtp_kpp_batched_workspace_bytes(n, d, l, batch). */
 int64_t mtp_kpp_batched_workspace_bytes(int64_t n, int d, int l, int batch);

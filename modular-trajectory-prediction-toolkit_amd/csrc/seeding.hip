@@ -680,10 +680,11 @@ static constexpr int KPP_POT_TS = KPP_GB;
 
 __global__ __launch_bounds__(64) void k_kpp_pot_blocks(const float *__restrict__ rows0, int64_t n, int n_rows,
                                                        size_t bstride, float *part0, int64_t nb,
-                                                       const double *pot64_0, double eps) {
+                                                       const double *pot64_0, double eps, size_t part_stride,
+                                                       int64_t part_pitch) {
     __shared__ __attribute__((aligned(16))) float tile[KPP_POT_TS];
     const float *rows = kpp_at(rows0, bstride, blockIdx.z);
-    float *part = kpp_at(part0, bstride, blockIdx.z);
+    float *part = kpp_at(part0, part_stride, blockIdx.z);  // block sums of row j at part[j * part_pitch + block]
     const int tid = threadIdx.x;
     const int64_t m_main = n & ~(int64_t)3;
     const int64_t off = (int64_t)blockIdx.x * KPP_GB;
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(64) void k_kpp_pot_blocks(const float *__restrict__
     const float h = pair ? acc : acc + o4;          // lanes 0..3
     const float t = h + __shfl_down(h, 1, 8);       // lanes 0 and 2: h0 + h1, h2 + h3
     const float y = t + __shfl_down(t, 2, 8);       // lane 0
-    if (l8 == 0) part[(size_t)row * nb + blockIdx.x] = y;
+    if (l8 == 0) part[(size_t)row * part_pitch + blockIdx.x] = y;
 }
 
 // the first centre's potential (one row per restart) in sdot's order; result -> part[0]
@@ -797,10 +798,108 @@ extern "C" int mtp_blas_order_rowsums_f32(const float *rows, int l, int64_t n, f
     const int64_t nb = kpp_pot_blocks(n);
     if (nb > 0) {
         hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)nb, (unsigned)l, 1), dim3(64), 0, s, rows, n, l, (size_t)0, part, nb,
-                           (const double *)nullptr, 0.0);
+                           (const double *)nullptr, 0.0, (size_t)0, nb);
         MTP_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_kpp_pot_combine, dim3(1), dim3(64), 0, s, rows, n, l, part, nb, out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+// ---- the same orders for rows that are split over ranks at multiples of 4096 points (pccs_accel.seeding.
+// kmeans_plusplus_sharded): every rank forms the block sums of its piece, the pieces' block sums are gathered and
+// added in order.  Oracle: oracle.c orc_sgemv_t_block_sums / orc_sdot_carry (checked piecewise == whole on the CPU). ----
+extern "C" int64_t mtp_blas_order_blocks(int64_t n) { return n > 0 ? kpp_pot_blocks(n) : 0; }
+
+// part[b][j][nb] = the sum of the n & 3 trailing points of row j of restart b
+__global__ void k_blas_tail_sums(const float *__restrict__ rows, int64_t n, int64_t total_rows, float *part, int64_t nb) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= total_rows) return;
+    const int tail_n = (int)(n & 3);
+    const float *tail = rows + (size_t)r * n + (n - tail_n);
+    float t = 0.f;
+    if (tail_n == 3) t = (tail[0] + tail[1]) + tail[2];
+    else if (tail_n == 2) t = tail[0] + tail[1];
+    else if (tail_n == 1) t = tail[0];
+    part[(size_t)r * (nb + 1) + nb] = t;
+}
+
+extern "C" int mtp_blas_order_block_sums_f32(const float *rows, int l, int64_t n, int batch, float *part, void *stream) {
+    MTP_REQUIRE(part && (rows || n == 0), "mtp_blas_order_block_sums: null pointer");
+    MTP_REQUIRE(l >= 1 && l <= KPP_MAX_L && n >= 0 && batch >= 1 && batch <= 65535,
+                "mtp_blas_order_block_sums: bad shape l=%d n=%lld batch=%d", l, (long long)n, batch);
+    hipStream_t s = mtp_stream(stream);
+    const int64_t nb = mtp_blas_order_blocks(n);
+    if (nb > 0) {
+        hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)nb, (unsigned)l, (unsigned)batch), dim3(64), 0, s, rows, n, l,
+                           (size_t)l * n * 4, part, nb, (const double *)nullptr, 0.0, (size_t)l * (nb + 1) * 4, nb + 1);
+        MTP_LAUNCH_CHECK();
+    }
+    const int64_t total_rows = (int64_t)batch * l;
+    hipLaunchKernelGGL(k_blas_tail_sums, dim3((unsigned)((total_rows + 63) / 64)), dim3(64), 0, s, rows, n, total_rows, part, nb);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+// out[r] = ((0 + part[r][0]) + part[r][1]) + ... in float, one thread per row
+__global__ void k_blas_combine(const float *__restrict__ part, int64_t m, int64_t total_rows, float *out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= total_rows) return;
+    const float *p = part + (size_t)r * m;
+    float y = 0.f;
+    for (int64_t j = 0; j < m; ++j) y = y + p[j];
+    out[r] = y;
+}
+
+extern "C" int mtp_blas_order_combine_f32(const float *part, int64_t m, int64_t total_rows, float *out, void *stream) {
+    MTP_REQUIRE(part && out && m >= 1 && total_rows >= 1, "mtp_blas_order_combine: bad arguments");
+    hipLaunchKernelGGL(k_blas_combine, dim3((unsigned)((total_rows + 63) / 64)), dim3(64), 0, mtp_stream(stream), part, m,
+                       total_rows, out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+// sdot, piecewise: one wave per row; lane e = 16 a + l is accumulator a, lane l
+__global__ __launch_bounds__(64) void k_blas_sdot_carry(const float *__restrict__ x0, int64_t row_stride, int64_t main_local,
+                                                        int64_t left_over, float *acc0, int finish, float *out) {
+    const float *x = x0 + (size_t)blockIdx.x * row_stride;
+    float *accp = acc0 + (size_t)blockIdx.x * 64;
+    const int lane = threadIdx.x, a = lane >> 4, l = lane & 15;
+    float acc = accp[lane];
+    int64_t i = 0;
+    for (; i + 512 <= main_local; i += 512) {  // eight independent loads in flight per lane
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = x[i + 64 * e + lane];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = acc + v[e];
+    }
+    for (; i < main_local; i += 64) acc = acc + x[i + lane];
+    accp[lane] = acc;
+    if (!finish) return;
+    const int64_t chunk = left_over & ~(int64_t)31;  // 0 or 32
+    float w = acc + __shfl_down(acc, 8, 16);  // lanes l < 8 of each accumulator: 16 -> 8
+    if (chunk && l < 8) w = w + x[main_local + 8 * a + l];
+    const int l7 = lane & 7;
+    const float c = ((__shfl(w, l7) + __shfl(w, 16 + l7)) + __shfl(w, 32 + l7)) + __shfl(w, 48 + l7);
+    const float h = c + __shfl_down(c, 4, 8);
+    const float t = h + __shfl_down(h, 1, 8);
+    const float y = t + __shfl_down(t, 2, 8);
+    if (lane == 0) {
+        double dot = (double)y;
+        for (int64_t jj = chunk; jj < left_over; ++jj) dot += (double)x[main_local + jj];
+        out[blockIdx.x] = (float)dot;
+    }
+}
+
+extern "C" int mtp_blas_order_sdot_carry_f32(const float *x, int64_t row_stride, int batch, int64_t main_local,
+                                             int64_t left_over, float *acc, int finish, float *out, void *stream) {
+    MTP_REQUIRE(acc && batch >= 1 && (x || (main_local == 0 && (!finish || left_over == 0))),
+                "mtp_blas_order_sdot_carry: null pointer");
+    MTP_REQUIRE(main_local >= 0 && main_local % 64 == 0 && left_over >= 0 && left_over < 64 && (!finish || out),
+                "mtp_blas_order_sdot_carry: main_local must be a multiple of 64 and left_over < 64");
+    hipLaunchKernelGGL(k_blas_sdot_carry, dim3((unsigned)batch), dim3(64), 0, mtp_stream(stream), x, row_stride, main_local,
+                       left_over, acc, finish, out);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
@@ -1056,7 +1155,7 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
                 pot_tail = (int)(n & 3);
                 if (pot_nb > 0)
                     hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)pot_nb, (unsigned)n_prev, (unsigned)batch), dim3(64), 0, s,
-                                       rows_cur, n, n_prev, w.stride, w.pot_part, pot_nb, w.pot64, pot_eps);
+                                       rows_cur, n, n_prev, w.stride, w.pot_part, pot_nb, w.pot64, pot_eps, w.stride, pot_nb);
             }
             MTP_LAUNCH_CHECK();
         }

@@ -28,8 +28,13 @@ def world():
     return 0, 1
 
 
-def shard_bounds(n_total, rank, world_size):
-    """Contiguous row block of ``rank``: the first n_total % world_size ranks get one extra row."""
+def shard_bounds(n_total, rank, world_size, align=1):
+    """Contiguous row block of ``rank``: the first n_total % world_size ranks get one extra row.  ``align`` > 1:
+    every block but the last starts and ends at a multiple of ``align`` (blocks of ``align`` rows are dealt out
+    instead of rows; ``seeding.POT_ALIGN`` for the sharded seeding's OpenBLAS-order potentials)."""
+    if align > 1:
+        lo, hi = shard_bounds((n_total + align - 1) // align, rank, world_size)
+        return min(lo * align, n_total), min(hi * align, n_total)
     base, rem = divmod(n_total, world_size)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
@@ -426,7 +431,8 @@ def is_same_clustering_sharded(l1, l2, k, collective, group=None):
 
 def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_iter=300, check_every=1, group=None,
                        force_collectives=False, lagged_steps=0, n_clusters=None, n_init=20, random_state=None,
-                       lloyd_ops=None, seed_ops=None, stats=None, comm=None, stats_order=None, seqsum=None):
+                       lloyd_ops=None, seed_ops=None, stats=None, comm=None, stats_order=None, seqsum=None,
+                       pot_order=None):
     """sklearn ``KMeans.fit`` over row-sharded, un-centred points (one process per GPU): global mean /
     tolerance by all-reduce of column sums, then
 
@@ -441,6 +447,9 @@ def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_it
     rank r - 1 stopped (``mtp_col_seqsum_carry_f32``, one small broadcast per rank and pass), so the centred points and
     the tolerance are those of the one-GPU fit and of sklearn, bit for bit; "f64": double sums, one all-reduce each
     (default when the ``stats`` test hooks are given).  ``seqsum``: test hook for the "numpy" order.
+    ``pot_order``: the order of the seeding's float32 potentials (``seeding.kmeans_plusplus_sharded``): "openblas"
+    (default when every rank's first row is a multiple of 4096, ``shard_bounds(..., align=seeding.POT_ALIGN)``) picks
+    sklearn's seeds bit for bit; "f64" works for any split.
     ``comm``: an ``RcclComm``; the Lloyd runs then go through ``mtp_lloyd_sharded_f32`` (loop and all-reduce inside
     the library) instead of the step-level driver ``ShardedLloyd``.
     Returns dict(labels (local), centers, inertia, n_iter, tol_abs).  ``lloyd_ops`` / ``seed_ops`` / ``stats``
@@ -518,7 +527,7 @@ def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_it
     # the draws of every restart, in sklearn's order (seeding consumes the stream, Lloyd does not)
     draws = [seeding.draw(rs, n_total, n_clusters) for _ in range(n_init)]
     c0s, _ = seeding.kmeans_plusplus_sharded(Xc, row_offset, n_total, n_clusters, draws, group=group, ops=seed_ops,
-                                             force_collectives=force_collectives)
+                                             force_collectives=force_collectives, pot_order=pot_order)
     best = None
     for r in range(n_init):
         labels, inertia, centers, n_iter = lloyd(c0s[r].contiguous())

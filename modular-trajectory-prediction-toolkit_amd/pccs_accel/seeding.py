@@ -158,6 +158,38 @@ class DeviceSeedOps:
         return rows, pot
 
 
+    def block_sums(self, rows):
+        """rows float32 [B, L, n] -> float32 [B, L, nb + 1]: OpenBLAS sgemv_t's 4096-point block sums of every row and,
+        last, the sum of its n & 3 trailing points (``mtp_blas_order_block_sums_f32``)."""
+        b, l, n = rows.shape
+        nb = int(lib().mtp_blas_order_blocks(n))
+        part = torch.empty((b, l, nb + 1), dtype=torch.float32, device=rows.device)
+        with torch.cuda.device(rows.device):
+            check(lib().mtp_blas_order_block_sums_f32(ptr(rows) if n else None, l, n, b, ptr(part), stream_ptr()),
+                  "mtp_blas_order_block_sums_f32")
+        return part
+
+    def combine(self, parts):
+        """float32 [R, m] -> [R]: the entries of a row added one after the other in float (``mtp_blas_order_combine_f32``)."""
+        parts = parts.contiguous()
+        out = torch.empty(parts.shape[0], dtype=torch.float32, device=parts.device)
+        with torch.cuda.device(parts.device):
+            check(lib().mtp_blas_order_combine_f32(ptr(parts), parts.shape[1], parts.shape[0], ptr(out), stream_ptr()),
+                  "mtp_blas_order_combine_f32")
+        return out
+
+    def sdot_carry(self, x, main_local, left_over, acc, finish):
+        """One rank's piece of OpenBLAS' sdot over rows x float32 [B, n_local]: acc float32 [B, 64] is continued in
+        place over the first main_local points; with ``finish`` the left_over points behind them are taken in and the
+        sums float32 [B] returned (``mtp_blas_order_sdot_carry_f32``)."""
+        b = acc.shape[0]
+        out = torch.empty(b, dtype=torch.float32, device=acc.device) if finish else None
+        with torch.cuda.device(acc.device):
+            check(lib().mtp_blas_order_sdot_carry_f32(ptr(x) if x.numel() else None, x.stride(0) if x.numel() else 0, b,
+                                                      int(main_local), int(left_over), ptr(acc), 1 if finish else 0,
+                                                      ptr(out), stream_ptr()), "mtp_blas_order_sdot_carry_f32")
+        return out
+
     def count_below(self, closest, thresholds):
         """counts int64 [B, L]: this rank's cumulative sums of closest[b] (double) below thresholds[b, l]."""
         b, n = closest.shape
@@ -181,8 +213,11 @@ def _first_argmin(v):
     return torch.where(v == m, pos, torch.full_like(pos, l)).min(dim=1).values
 
 
+POT_ALIGN = 4096  # OpenBLAS sgemv_t's block length: the shards' first rows must be multiples of it for pot_order="openblas"
+
+
 def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, group=None, ops=None,
-                            force_collectives=False, packed=True):
+                            force_collectives=False, packed=True, pot_order=None):
     """k-means++ (sklearn cluster/_kmeans.py:174-272, unit weights) for ``len(draws)`` restarts in lock
     step over ROW-SHARDED centred points: this rank holds rows [row_offset, row_offset + n_local) of
     the n_total (consecutive blocks in rank order).  ``draws``: one ``draw()`` result per restart,
@@ -200,6 +235,12 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
       (B) each rank computes the candidates' distances to its points with the fp64 matrix-pipe kernel; the
           ranks' parts of the [B, L] potentials are gathered and added in rank order: the totals, and every
           rank's part of the chosen row's total for the next step's (A).
+    ``pot_order``: "openblas" -- the float32 potentials are added in the reference stack's order (NumPy + OpenBLAS
+    sgemv_t / sdot, see ``kmeans_plusplus``): every rank forms the 4096-point block sums of its piece of the candidate
+    rows (``mtp_blas_order_block_sums_f32``), they travel with (B) and are added in rank order; the first centre's
+    sdot accumulators are handed from rank to rank once.  Needs every rank's first row at a multiple of 4096
+    (``dist.shard_bounds(..., align=POT_ALIGN)``); then the seeds are sklearn's bit for bit, as on one GPU.
+    "f64": double sums (any row split).  Default: "openblas" when the split allows it.
     ``packed=False``: three collectives per centre (counts all-reduced, rows fetched by index, potentials as in (B)).
     Returns (centres float32 [B, K, D], indices int64 [B, K]), replicated.  Needs D % 16 == 0 and at most 8
     local trials (K <= 1096)."""
@@ -230,6 +271,25 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
         if int(los[0]) != 0 or int(his[-1]) != n_total or bool((los[1:] != his[:-1]).any()):
             raise ValueError("the ranks must hold consecutive row blocks of the n_total rows, in rank order")
 
+    if collective:
+        aligned = bool(((los % POT_ALIGN == 0) | (sizes == 0)).all())  # empty pieces sit at the end
+    else:
+        los = torch.zeros(1, dtype=torch.int64, device=dev)
+        sizes = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        aligned = True
+    if pot_order is None:
+        pot_order = "openblas" if (aligned and hasattr(ops, "block_sums")) else "f64"
+    if pot_order not in ("openblas", "f64"):
+        raise ValueError(f"pot_order must be 'openblas' or 'f64', got {pot_order!r}")
+    if pot_order == "openblas" and not aligned:
+        raise ValueError(f"pot_order='openblas' needs every rank's first row at a multiple of {POT_ALIGN}")
+    blas = pot_order == "openblas"
+    nranks = ws if collective else 1
+    sizes_h = [int(v) for v in sizes.cpu()]
+    los_h = [int(v) for v in los.cpu()]
+    if blas:
+        nb_pad = max(int(((m & ~3) + POT_ALIGN - 1) // POT_ALIGN) for m in sizes_h)  # blocks of the longest piece
+
     def fetch_rows(idx):
         """X[idx] for GLOBAL row indices idx [B, m] -> [B, m, D] on every rank (owners contribute, one all-reduce)."""
         if n_local:
@@ -243,23 +303,57 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
             pdist.all_reduce_sum(rows, group)
         return rows
 
-    def total_potentials(pot):
-        """(global potentials [B, m], every rank's part [W, B, m]); parts added in rank order."""
-        if not collective:
-            return pot, pot[None]
-        parts = gather(pot)
+    def total_potentials(pot, rows=None):
+        """(global potentials [B, m] in double, every rank's part [W, B, m], float32 potentials in OpenBLAS order or
+        None); parts added in rank order.  ``rows`` [B, m, n_local]: this rank's piece of the candidate rows."""
+        payload = pot
+        if blas and rows is not None:
+            # [double part | the piece's block sums, zero padded | its tail sum]: one exchange for both
+            bs = ops.block_sums(rows)
+            m = rows.shape[1]
+            payload = torch.zeros((b, m, 1 + nb_pad + 1), dtype=torch.float64, device=dev)
+            payload[..., 0] = pot
+            payload[..., 1:bs.shape[2]] = bs[..., :-1].to(torch.float64)
+            payload[..., -1] = bs[..., -1].to(torch.float64)
+        every = gather(payload) if collective else payload[None]
+        parts = every[..., 0] if payload is not pot else every
         tot = parts[0].clone()
         for r in range(1, parts.shape[0]):
             tot += parts[r]
-        return tot, parts
+        pot32 = None
+        if payload is not pot:
+            # the pieces' block sums side by side in rank order, then added one after the other in float
+            seq = every[..., 1:].to(torch.float32).permute(1, 2, 0, 3).reshape(b * rows.shape[1], -1)
+            pot32 = ops.combine(seq).view(b, rows.shape[1])
+        return tot, parts, pot32
+
+    def first_potential(closest):
+        """[1, n] @ [n] of the first centre's closest row in OpenBLAS' sdot order: the 64 accumulators go from rank to
+        rank over the first n_total & -64 points, the rank holding the last point finishes."""
+        n64 = (n_total & -32) & -64
+        left_over = n_total - n64
+        acc = torch.zeros((b, 64), dtype=torch.float32, device=dev)
+        out = torch.zeros(b, dtype=torch.float32, device=dev)
+        finisher = max(r for r in range(nranks) if sizes_h[r] > 0)
+        for r in range(nranks):
+            if r == rank or not collective:
+                main_local = max(0, min(los_h[r] + sizes_h[r], n64) - los_h[r])
+                res = ops.sdot_carry(closest, main_local, left_over, acc, r == finisher)
+                if r == finisher:
+                    out = res
+            if collective:
+                pdist.broadcast_from(acc, r, group)
+        if collective:
+            pdist.broadcast_from(out, finisher, group)
+        return out
 
     yy = ops.row_sqnorm(X_local)
     indices = torch.empty((b, n_clusters), dtype=torch.int64, device=dev)
     rows, pot = ops.candidate_dists(X_local, yy, fetch_rows(ids0[:, None]), None)
-    pot, parts = total_potentials(pot)
+    pot, parts, _ = total_potentials(pot)
     lower_tot = parts[:rank, :, 0].sum(dim=0)  # the lower ranks' totals of the closest-distance row
     closest = rows[:, 0, :].contiguous()
-    cur_pot = pot[:, 0].to(torch.float32)  # sklearn's potentials are float32
+    cur_pot = first_potential(closest) if blas else pot[:, 0].to(torch.float32)  # sklearn's potentials are float32
     indices[:, 0] = ids0
     bad = torch.zeros((), dtype=torch.bool, device=dev)
     if n_clusters > 1:
@@ -290,8 +384,9 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
             idx = cnt.clamp(max=n_total - 1)
             cand = fetch_rows(idx)
         rows, pot = ops.candidate_dists(X_local, yy, cand.contiguous(), closest)
-        pot, parts = total_potentials(pot)
-        pot32 = pot.to(torch.float32)
+        pot, parts, pot32 = total_potentials(pot, rows)
+        if pot32 is None:
+            pot32 = pot.to(torch.float32)
         best = _first_argmin(pot32)
         closest = rows[ar, best].contiguous()
         cur_pot = pot32[ar, best]
@@ -299,5 +394,5 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
         indices[:, c] = idx[ar, best]
     if collective and packed and bool(bad):
         return kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, group=group, ops=ops,
-                                       force_collectives=force_collectives, packed=False)
+                                       force_collectives=force_collectives, packed=False, pot_order=pot_order)
     return fetch_rows(indices), indices

@@ -381,3 +381,51 @@ void orc_col_seqsum_f32(const float *X, int64_t n, int d, const float *center, c
         }
     }
 }
+
+/* The same orders for a row that is split into consecutive pieces at multiples of 4096 points (row-sharded
+ * points, one piece per rank): sgemv_t's 4096-point block sums of one piece (part[j][0 .. nb-1], nb =
+ * ceil((n & -4) / 4096)) and the sum of its n & 3 trailing points (part[j][nb]; only the last piece has any);
+ * the row's sum is y = 0; y += every block sum in order; y += the tail -- orc_rowsums_sgemv_t, piecewise. */
+void orc_sgemv_t_block_sums(const float *rows, int l_rows, int64_t n, float *part) {
+    const int64_t m3 = n & 3, m_main = n - m3;
+    const int64_t nb = (m_main + 4095) / 4096;
+    for (int j = 0; j < l_rows; ++j) {
+        const float *x = rows + (size_t)j * n;
+        const int in_pair = (l_rows & 2) && j >= 4 * (l_rows >> 2) && j < 4 * (l_rows >> 2) + 2;
+        float *p = part + (size_t)j * (nb + 1);
+        for (int64_t b = 0; b < nb; ++b) {
+            const int64_t off = b * 4096;
+            const int64_t len = (m_main - off) < 4096 ? (m_main - off) : 4096;
+            p[b] = in_pair ? gemv_block4(x + off, len) : gemv_block8(x + off, len);
+        }
+        float t = 0.0f;
+        if (m3 == 3) t = (x[m_main] + x[m_main + 1]) + x[m_main + 2];
+        else if (m3 == 2) t = x[m_main] + x[m_main + 1];
+        else if (m3 == 1) t = x[m_main];
+        p[nb] = t;
+    }
+}
+
+/* sdot over a piece of the row: acc[64] (accumulator a, lane l at 16 a + l) continues over the piece's share of
+ * the first n_total & -64 points (main_local of them, a multiple of 64); the last piece (finish != 0) then takes
+ * the left-over points (fewer than 64: a chunk of 32 if there is one, the rest in double) and returns the sum. */
+float orc_sdot_carry(const float *x, int64_t main_local, int64_t left_over, float *acc, int finish) {
+    for (int64_t i = 0; i < main_local; i += 64)
+        for (int e = 0; e < 64; ++e) acc[e] += x[i + e];
+    if (!finish) return 0.0f;
+    const int64_t chunk = left_over & -32;  /* 0 or 32 */
+    double dot = 0.0;
+    {
+        float a8[4][8];
+        for (int a = 0; a < 4; ++a)
+            for (int l = 0; l < 8; ++l) a8[a][l] = acc[16 * a + l] + acc[16 * a + l + 8];
+        if (chunk)
+            for (int a = 0; a < 4; ++a)
+                for (int l = 0; l < 8; ++l) a8[a][l] += x[main_local + 8 * a + l];
+        float c[8];
+        for (int l = 0; l < 8; ++l) c[l] = ((a8[0][l] + a8[1][l]) + a8[2][l]) + a8[3][l];
+        dot = (double)fold8(c);
+    }
+    for (int64_t i = chunk; i < left_over; ++i) dot += (double)x[main_local + i];
+    return (float)dot;
+}

@@ -355,6 +355,70 @@ def test_sharded_seeding_matches_oracle(world, packed, tmp_path):
             assert np.array_equal(p["centers"][r], want[r][0])
 
 
+class BlasSeedOps(NumpySeedOps):
+    """NumpySeedOps plus the piecewise OpenBLAS-order sums (oracle.c's restatements of sgemv_t / sdot)."""
+
+    def block_sums(self, rows):
+        r = rows.numpy()
+        return torch.from_numpy(np.stack([O.sgemv_t_block_sums(r[i]) for i in range(r.shape[0])]))
+
+    def combine(self, parts):
+        return torch.from_numpy(O.combine_block_sums(parts.numpy()))
+
+    def sdot_carry(self, x, main_local, left_over, acc, finish):
+        a = acc.numpy()  # shares memory: updated in place
+        out = np.zeros(a.shape[0], dtype=np.float32)
+        for i in range(a.shape[0]):
+            out[i] = O.sdot_carry(x[i].numpy() if x.shape[1] else np.zeros(0, np.float32), main_local, left_over, a[i],
+                                  finish)
+        return torch.from_numpy(out) if finish else None
+
+
+def _blas_seed_case(n):
+    X = datagen.make_encodings(77, n, 16, 5, 1500, 900)
+    return np.ascontiguousarray(X - X.mean(axis=0))
+
+
+def _blas_seed_worker(rank, world, port, out_dir, n):
+    sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pccs_accel import dist as pdist
+    from pccs_accel import seeding
+    Xc = _blas_seed_case(n)
+    k, b = 7, 2
+    rs = np.random.RandomState(23)
+    draws = [seeding.draw(rs, n, k) for _ in range(b)]
+    lo, hi = pdist.shard_bounds(n, rank, world, align=seeding.POT_ALIGN)
+    centers, indices = seeding.kmeans_plusplus_sharded(torch.from_numpy(Xc[lo:hi].copy()), lo, n, k, draws,
+                                                       ops=BlasSeedOps(), force_collectives=True)
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), centers=centers.numpy(), indices=indices.numpy())
+    if world > 1:  # a split that is not block-aligned cannot keep the order and says so (on every rank)
+        lo, hi = pdist.shard_bounds(n, rank, world)
+        with pytest.raises(ValueError, match="multiple of"):
+            seeding.kmeans_plusplus_sharded(torch.from_numpy(Xc[lo:hi].copy()), lo, n, k, draws, ops=BlasSeedOps(),
+                                            pot_order="openblas")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(1, 9001), (2, 3 * 4096 + 1003), (3, 3 * 4096 + 1003), (3, 2 * 4096), (2, 4096 + 66)])
+def test_sharded_seeding_in_openblas_order(world, n, tmp_path):
+    """Row-sharded k-means++ with the float32 potentials added as NumPy + OpenBLAS add them (sgemv_t's 4096-point
+    blocks formed per rank and combined in rank order; sdot's 64 accumulators handed from rank to rank for the first
+    centre): with block-aligned shards -- an empty last rank and a 2-point sdot tail among the cases -- every rank
+    picks the seeds of the oracle's OpenBLAS-order k-means++, which fixture G14 pins to sklearn's own."""
+    mp.spawn(_blas_seed_worker, args=(world, _free_port(), str(tmp_path), n), nprocs=world, join=True)
+    Xc = _blas_seed_case(n)
+    rs = np.random.RandomState(23)
+    want = [O.kmeans_plusplus(Xc, 7, rs, pot="blas_model") for _ in range(2)]
+    parts = [np.load(tmp_path / f"s{r}.npz") for r in range(world)]
+    for p in parts:
+        for r in range(2):
+            assert np.array_equal(p["indices"][r], want[r][1])
+            assert np.array_equal(p["centers"][r], want[r][0])
+
+
 def _fit_worker(rank, world, port, out_dir, numpy_stats=False):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -168,12 +168,12 @@ def test_in_library_rccl_loop(which, tmp_path, gpu_device):
     assert p["phase"].shape == (3,) and (p["phase"] >= 0).all() and p["phase"][0] > 0
 
 
-def _pp_case():
-    X = datagen.make_encodings(51, 6007, 96, 24, 1500, 900)
+def _pp_case(n=6007):
+    X = datagen.make_encodings(51, n, 96, 24, 1500, 900)
     return np.ascontiguousarray(X)
 
 
-def _pp_worker(rank, world, port, backend, out_dir):
+def _pp_worker(rank, world, port, backend, out_dir, n=6007, order="f64"):
     import faulthandler
     faulthandler.dump_traceback_later(120, exit=True)
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "tests", "golden")]
@@ -188,16 +188,17 @@ def _pp_worker(rank, world, port, backend, out_dir):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from pccs_accel import dist as pdist
     from pccs_accel import seeding
-    X = _pp_case()
+    X = _pp_case(n)
     n, k, b = X.shape[0], 24, 5
-    lo, hi = pdist.shard_bounds(n, rank, world)
+    lo, hi = pdist.shard_bounds(n, rank, world, align=seeding.POT_ALIGN if order == "openblas" else 1)
     Xl = torch.from_numpy(X[lo:hi].copy()).to(dev)
     # seeding alone, on data centred with the global mean (what the fit passes it)
     Xc = torch.from_numpy((X - X.mean(axis=0, dtype=np.float64).astype(np.float32))[lo:hi].copy()).to(dev)
     rs = np.random.RandomState(23)
     draws = [seeding.draw(rs, n, k) for _ in range(b)]
-    centers, indices = seeding.kmeans_plusplus_sharded(Xc, lo, n, k, draws, force_collectives=True)
-    fit = pdist.kmeans_fit_sharded(Xl, n, row_offset=lo, n_clusters=k, n_init=b, random_state=23, force_collectives=True)
+    centers, indices = seeding.kmeans_plusplus_sharded(Xc, lo, n, k, draws, force_collectives=True, pot_order=order)
+    fit = pdist.kmeans_fit_sharded(Xl, n, row_offset=lo, n_clusters=k, n_init=b, random_state=23, force_collectives=True,
+                                   pot_order=order)
     np.savez(os.path.join(out_dir, f"p{rank}.npz"), seed_centers=centers.cpu().numpy(), seed_indices=indices.cpu().numpy(),
              labels=fit["labels"].cpu().numpy(), centers=fit["centers"].cpu().numpy(), inertia=fit["inertia"],
              n_iter=fit["n_iter"])
@@ -205,20 +206,25 @@ def _pp_worker(rank, world, port, backend, out_dir):
     faulthandler.cancel_dump_traceback_later()
 
 
-@pytest.mark.parametrize("backend,world", [("gloo", 2), ("gloo", 3), ("nccl", 1)])
-def test_sharded_seeding_and_full_fit_match_single_gpu(backend, world, tmp_path, gpu_device):
+@pytest.mark.parametrize("backend,world,n,order", [("gloo", 2, 6007, "f64"), ("gloo", 3, 6007, "f64"),
+                                                   ("nccl", 1, 6007, "f64"), ("nccl", 1, 6007, "openblas"),
+                                                   ("gloo", 2, 3 * 4096 + 1003, "openblas"),
+                                                   ("gloo", 3, 2 * 4096 + 70, "openblas")])
+def test_sharded_seeding_and_full_fit_match_single_gpu(backend, world, n, order, tmp_path, gpu_device):
     """k-means++ and the whole KMeans(n_clusters, n_init).fit over row-sharded points with the real kernels
     (mtp_kpp_candidate_dists_f32 + the step-level Lloyd entries) against the one-GPU path: same seeds for every
-    restart, same labels / iteration count, centres and inertia to rounding."""
+    restart, same labels / iteration count, centres and inertia to rounding -- with double potentials (any split)
+    and with the float32 potentials in the reference stack's order (4096-aligned shards: block sums per rank combined
+    in rank order, the sdot accumulators handed on), which is the one-GPU default that fixture G14 pins to sklearn."""
     from pccs_accel import clustering, seeding
-    mp.spawn(_pp_worker, args=(world, _free_port(), backend, str(tmp_path)), nprocs=world, join=True)
-    X = _pp_case()
+    mp.spawn(_pp_worker, args=(world, _free_port(), backend, str(tmp_path), n, order), nprocs=world, join=True)
+    X = _pp_case(n)
     n, k, b = X.shape[0], 24, 5
     Xc = torch.from_numpy(X - X.mean(axis=0, dtype=np.float64).astype(np.float32)).to(gpu_device)
     rs = np.random.RandomState(23)
     draws = [seeding.draw(rs, n, k) for _ in range(b)]
-    c1, i1 = seeding.kmeans_plusplus_batched(Xc, k, draws, pot_order="f64")  # the sharded seeding sums in double
-    single = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), k, n_init=b, random_state=23, pot_order="f64")
+    c1, i1 = seeding.kmeans_plusplus_batched(Xc, k, draws, pot_order=order)
+    single = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), k, n_init=b, random_state=23, pot_order=order)
     parts = [np.load(tmp_path / f"p{r}.npz") for r in range(world)]
     for p in parts:
         assert np.array_equal(p["seed_indices"], i1.cpu().numpy())

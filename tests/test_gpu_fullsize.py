@@ -107,9 +107,10 @@ def test_seeding_fullsize_sharded_equals_fused(big, gpu_device):
     KK.sub_rowvec_(Xc, (KK.col_sums(Xc) / n).to(torch.float32))
     rs = np.random.RandomState(3)
     draws = [(c, np.ascontiguousarray(u[:k - 1])) for c, u in (seeding.draw(rs, n, K) for _ in range(4))]
-    c_f, i_f = seeding.kmeans_plusplus_batched(Xc, k, draws, pot_order="f64")  # the sharded driver sums in double
-    c_s, i_s = seeding.kmeans_plusplus_sharded(Xc, 0, n, k, draws)
-    assert torch.equal(i_f, i_s) and torch.equal(c_f, c_s)
+    for order in ("f64", "openblas"):  # double potentials; float32 ones in the reference stack's order (block sums)
+        c_f, i_f = seeding.kmeans_plusplus_batched(Xc, k, draws, pot_order=order)
+        c_s, i_s = seeding.kmeans_plusplus_sharded(Xc, 0, n, k, draws, pot_order=order)
+        assert torch.equal(i_f, i_s) and torch.equal(c_f, c_s)
     idx = i_f.cpu().numpy()
     assert idx.min() >= 0 and idx.max() < n and all(len(set(r)) == k for r in idx)
     assert torch.equal(c_f[2], Xc[i_f[2]])

@@ -494,3 +494,46 @@ def test_classifier_targets_reject_out_of_range_labels(gpu_device):
         classifier_targets(np.array([0, 3, 1], dtype=np.int32), 3, device=gpu_device)
     with pytest.raises(IndexError):
         classifier_targets(np.array([0, -1], dtype=np.int32), 3, device=gpu_device)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 3, 64, 4097, 3 * 4096, 13291])
+def test_blas_order_piecewise_entries(n, gpu_device):
+    """The pieces the row-sharded seeding adds its float32 potentials from, against oracle.c's restatement of
+    OpenBLAS 0.3.29's sgemv_t / sdot (what NumPy calls for sklearn's ``closest @ sample_weight`` and
+    ``distance_to_candidates @ sample_weight``): 4096-point block sums + tail (mtp_blas_order_block_sums_f32), their
+    sequential combination (mtp_blas_order_combine_f32), and the sdot accumulators carried over pieces of a row
+    (mtp_blas_order_sdot_carry_f32) -- all bit for bit, pieces put together equal to the whole-row sums."""
+    from pccs_accel import seeding
+    ops = seeding.DeviceSeedOps()
+    rng = np.random.default_rng(n + 5)
+    b, l = 2, 3
+    rows = (rng.random((b, l, n), dtype=np.float32) * 40.0).astype(np.float32)
+    part = ops.block_sums(dev(rows, gpu_device)).cpu().numpy()
+    for i in range(b):
+        assert np.array_equal(part[i], O.sgemv_t_block_sums(rows[i]))
+    comb = ops.combine(dev(part.reshape(b * l, -1), gpu_device)).cpu().numpy().reshape(b, l)
+    assert np.array_equal(comb, O.combine_block_sums(part))
+    if n:
+        for i in range(b):
+            assert np.array_equal(comb[i], O.rowsums_blas_order(rows[i]))
+    # sdot: the first restart's rows cut into three pieces at multiples of 64 (what a 4096-aligned split gives)
+    x = np.ascontiguousarray(rows[:, 0, :])
+    n64 = n & -64
+    cuts = [0, min(n64, 64), min(n64, 4096), n]
+    acc = torch.zeros((b, 64), dtype=torch.float32, device=gpu_device)
+    acc_o = np.zeros((b, 64), dtype=np.float32)
+    last = max([j for j in range(3) if cuts[j + 1] > cuts[j]], default=2)
+    out = None
+    for j in range(last + 1):
+        lo, hi = cuts[j], cuts[j + 1]
+        piece = np.ascontiguousarray(x[:, lo:hi])
+        main_local = max(0, min(hi, n64) - lo)
+        res = ops.sdot_carry(dev(piece, gpu_device).clone(), main_local, n - n64, acc, j == last)
+        want = [O.sdot_carry(piece[i], main_local, n - n64, acc_o[i], j == last) for i in range(b)]
+        assert np.array_equal(acc.cpu().numpy(), acc_o)
+        if j == last:
+            out = res.cpu().numpy()
+            assert np.array_equal(out, np.array(want, dtype=np.float32))
+    for i in range(b):
+        assert out[i] == O.sum_sdot_order(x[i])
