@@ -266,6 +266,10 @@ int mtp_blas_order_rowsums_f32(const float *rows, int l, int64_t n, float *out, 
  * points, one piece per rank (pccs_accel.seeding.kmeans_plusplus_sharded).  sgemv_t: a rank forms the 4096-point
  * block sums of its piece and the sum of its n & 3 trailing points (only the last piece has any),
  *   part [batch][l][nb + 1], nb = mtp_blas_order_blocks(n);
+ * pot64 (optional, [batch][l] double sums of the WHOLE rows) and eps: only the rows whose double sum is within
+ * (1 + eps) / (1 - eps) of the restart's smallest are walked (the only ones that can hold the smallest float32
+ * sum when eps covers the chains' rounding, (1100 + blocks) * 2^-23); the block sums of the others are left as
+ * the caller initialised them;
  * the pieces' parts are gathered, laid side by side in rank order and added one after the other in float
  * (mtp_blas_order_combine_f32: out[r] = sum over part[r][0 .. m), total_rows rows) -- the additions of
  * `rows @ sample_weight` (sklearn cluster/_kmeans.py:252) in OpenBLAS' order, whatever the number of ranks.
@@ -273,7 +277,8 @@ int mtp_blas_order_rowsums_f32(const float *rows, int l, int64_t n, float *out, 
  * (main_local of them on this rank, a multiple of 64); the rank holding the last point passes finish = 1 and the
  * left_over = n_total - (n_total & -32 & -64) points that follow, and receives out [batch]. */
 int64_t mtp_blas_order_blocks(int64_t n);
-int mtp_blas_order_block_sums_f32(const float *rows, int l, int64_t n, int batch, float *part, void *stream);
+int mtp_blas_order_block_sums_f32(const float *rows, int l, int64_t n, int batch, const double *pot64, double eps,
+                                  float *part, void *stream);
 int mtp_blas_order_combine_f32(const float *part, int64_t m, int64_t total_rows, float *out, void *stream);
 int mtp_blas_order_sdot_carry_f32(const float *x, int64_t row_stride, int batch, int64_t main_local, int64_t left_over,
                                   float *acc, int finish, float *out, void *stream);

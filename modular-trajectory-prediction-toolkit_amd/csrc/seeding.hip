@@ -681,7 +681,7 @@ static constexpr int KPP_POT_TS = KPP_GB;
 __global__ __launch_bounds__(64) void k_kpp_pot_blocks(const float *__restrict__ rows0, int64_t n, int n_rows,
                                                        size_t bstride, float *part0, int64_t nb,
                                                        const double *pot64_0, double eps, size_t part_stride,
-                                                       int64_t part_pitch) {
+                                                       int64_t part_pitch, size_t pot_stride) {
     __shared__ __attribute__((aligned(16))) float tile[KPP_POT_TS];
     const float *rows = kpp_at(rows0, bstride, blockIdx.z);
     float *part = kpp_at(part0, part_stride, blockIdx.z);  // block sums of row j at part[j * part_pitch + block]
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(64) void k_kpp_pot_blocks(const float *__restrict__
     const int nbk = (int)((m_main - off) < KPP_GB ? (m_main - off) : KPP_GB);  // a multiple of 4
     const int row = blockIdx.y;
     // rows that cannot hold the smallest potential are skipped (k_kpp_select applies the same test)
-    if (pot64_0 != nullptr && !kpp_contender(kpp_at(pot64_0, bstride, blockIdx.z), n_rows, row, eps)) return;
+    if (pot64_0 != nullptr && !kpp_contender(kpp_at(pot64_0, pot_stride, blockIdx.z), n_rows, row, eps)) return;
     const float *src = rows + (size_t)row * n + off;
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const float4 *src4 = reinterpret_cast<const float4 *>(src);
@@ -798,7 +798,7 @@ extern "C" int mtp_blas_order_rowsums_f32(const float *rows, int l, int64_t n, f
     const int64_t nb = kpp_pot_blocks(n);
     if (nb > 0) {
         hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)nb, (unsigned)l, 1), dim3(64), 0, s, rows, n, l, (size_t)0, part, nb,
-                           (const double *)nullptr, 0.0, (size_t)0, nb);
+                           (const double *)nullptr, 0.0, (size_t)0, nb, (size_t)0);
         MTP_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_kpp_pot_combine, dim3(1), dim3(64), 0, s, rows, n, l, part, nb, out);
@@ -824,7 +824,8 @@ __global__ void k_blas_tail_sums(const float *__restrict__ rows, int64_t n, int6
     part[(size_t)r * (nb + 1) + nb] = t;
 }
 
-extern "C" int mtp_blas_order_block_sums_f32(const float *rows, int l, int64_t n, int batch, float *part, void *stream) {
+extern "C" int mtp_blas_order_block_sums_f32(const float *rows, int l, int64_t n, int batch, const double *pot64, double eps,
+                                             float *part, void *stream) {
     MTP_REQUIRE(part && (rows || n == 0), "mtp_blas_order_block_sums: null pointer");
     MTP_REQUIRE(l >= 1 && l <= KPP_MAX_L && n >= 0 && batch >= 1 && batch <= 65535,
                 "mtp_blas_order_block_sums: bad shape l=%d n=%lld batch=%d", l, (long long)n, batch);
@@ -832,7 +833,7 @@ extern "C" int mtp_blas_order_block_sums_f32(const float *rows, int l, int64_t n
     const int64_t nb = mtp_blas_order_blocks(n);
     if (nb > 0) {
         hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)nb, (unsigned)l, (unsigned)batch), dim3(64), 0, s, rows, n, l,
-                           (size_t)l * n * 4, part, nb, (const double *)nullptr, 0.0, (size_t)l * (nb + 1) * 4, nb + 1);
+                           (size_t)l * n * 4, part, nb, pot64, eps, (size_t)l * (nb + 1) * 4, nb + 1, (size_t)l * 8);
         MTP_LAUNCH_CHECK();
     }
     const int64_t total_rows = (int64_t)batch * l;
@@ -841,20 +842,26 @@ extern "C" int mtp_blas_order_block_sums_f32(const float *rows, int l, int64_t n
     return MTP_OK;
 }
 
-// out[r] = ((0 + part[r][0]) + part[r][1]) + ... in float, one thread per row
-__global__ void k_blas_combine(const float *__restrict__ part, int64_t m, int64_t total_rows, float *out) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= total_rows) return;
-    const float *p = part + (size_t)r * m;
+// out[r] = ((0 + part[r][0]) + part[r][1]) + ... in float.  One wave per row: 64 entries are fetched with one
+// coalesced load (the next 64 are on their way meanwhile) and added one after the other from the lanes' registers.
+__global__ __launch_bounds__(64) void k_blas_combine(const float *__restrict__ part, int64_t m, float *out) {
+    const float *p = part + (size_t)blockIdx.x * m;
+    const int lane = threadIdx.x;
     float y = 0.f;
-    for (int64_t j = 0; j < m; ++j) y = y + p[j];
-    out[r] = y;
+    float v = lane < m ? p[lane] : 0.f;
+    for (int64_t j = 0; j < m; j += 64) {
+        const float vn = (j + 64 + lane < m) ? p[j + 64 + lane] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 64; ++t)  // entries beyond m are +0: y + 0 == y
+            y = y + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t));
+        v = vn;
+    }
+    if (lane == 0) out[blockIdx.x] = y;
 }
 
 extern "C" int mtp_blas_order_combine_f32(const float *part, int64_t m, int64_t total_rows, float *out, void *stream) {
-    MTP_REQUIRE(part && out && m >= 1 && total_rows >= 1, "mtp_blas_order_combine: bad arguments");
-    hipLaunchKernelGGL(k_blas_combine, dim3((unsigned)((total_rows + 63) / 64)), dim3(64), 0, mtp_stream(stream), part, m,
-                       total_rows, out);
+    MTP_REQUIRE(part && out && m >= 1 && total_rows >= 1 && total_rows <= 0x7fffffff, "mtp_blas_order_combine: bad arguments");
+    hipLaunchKernelGGL(k_blas_combine, dim3((unsigned)total_rows), dim3(64), 0, mtp_stream(stream), part, m, out);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
@@ -1155,7 +1162,7 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
                 pot_tail = (int)(n & 3);
                 if (pot_nb > 0)
                     hipLaunchKernelGGL(k_kpp_pot_blocks, dim3((unsigned)pot_nb, (unsigned)n_prev, (unsigned)batch), dim3(64), 0, s,
-                                       rows_cur, n, n_prev, w.stride, w.pot_part, pot_nb, w.pot64, pot_eps, w.stride, pot_nb);
+                                       rows_cur, n, n_prev, w.stride, w.pot_part, pot_nb, w.pot64, pot_eps, w.stride, pot_nb, w.stride);
             }
             MTP_LAUNCH_CHECK();
         }

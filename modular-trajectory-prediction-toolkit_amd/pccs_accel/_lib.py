@@ -61,7 +61,7 @@ SIGNATURES = {
     "mtp_blas_order_rowsums_workspace_bytes": (_i64, [_i64, _i32]),
     "mtp_blas_order_rowsums_f32": (_i32, [_vp, _i32, _i64, _vp, _vp, _sz, _vp]),
     "mtp_blas_order_blocks": (_i64, [_i64]),
-    "mtp_blas_order_block_sums_f32": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
+    "mtp_blas_order_block_sums_f32": (_i32, [_vp, _i32, _i64, _i32, _vp, _f64, _vp, _vp]),
     "mtp_blas_order_combine_f32": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "mtp_blas_order_sdot_carry_f32": (_i32, [_vp, _i64, _i32, _i64, _i64, _vp, _i32, _vp, _vp]),
     "mtp_kpp_candidate_dists_workspace_bytes": (_i64, [_i64, _i32, _i32]),

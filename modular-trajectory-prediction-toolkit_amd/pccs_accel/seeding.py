@@ -158,15 +158,19 @@ class DeviceSeedOps:
         return rows, pot
 
 
-    def block_sums(self, rows):
+    def block_sums(self, rows, pot64=None, eps=0.0):
         """rows float32 [B, L, n] -> float32 [B, L, nb + 1]: OpenBLAS sgemv_t's 4096-point block sums of every row and,
-        last, the sum of its n & 3 trailing points (``mtp_blas_order_block_sums_f32``)."""
+        last, the sum of its n & 3 trailing points (``mtp_blas_order_block_sums_f32``).  ``pot64`` float64 [B, L]
+        (the double sums of the whole rows) and ``eps``: rows that cannot hold the smallest float32 sum are skipped,
+        their block sums are zero."""
         b, l, n = rows.shape
         nb = int(lib().mtp_blas_order_blocks(n))
-        part = torch.empty((b, l, nb + 1), dtype=torch.float32, device=rows.device)
+        part = (torch.empty if pot64 is None else torch.zeros)((b, l, nb + 1), dtype=torch.float32, device=rows.device)
+        if pot64 is not None:
+            pot64 = pot64.contiguous()
         with torch.cuda.device(rows.device):
-            check(lib().mtp_blas_order_block_sums_f32(ptr(rows) if n else None, l, n, b, ptr(part), stream_ptr()),
-                  "mtp_blas_order_block_sums_f32")
+            check(lib().mtp_blas_order_block_sums_f32(ptr(rows) if n else None, l, n, b, ptr(pot64), float(eps), ptr(part),
+                                                      stream_ptr()), "mtp_blas_order_block_sums_f32")
         return part
 
     def combine(self, parts):
@@ -237,8 +241,10 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
           rank's part of the chosen row's total for the next step's (A).
     ``pot_order``: "openblas" -- the float32 potentials are added in the reference stack's order (NumPy + OpenBLAS
     sgemv_t / sdot, see ``kmeans_plusplus``): every rank forms the 4096-point block sums of its piece of the candidate
-    rows (``mtp_blas_order_block_sums_f32``), they travel with (B) and are added in rank order; the first centre's
-    sdot accumulators are handed from rank to rank once.  Needs every rank's first row at a multiple of 4096
+    rows (``mtp_blas_order_block_sums_f32``), a third all-gather (B') brings them together and they are added in rank
+    order; the first centre's sdot accumulators are handed from rank to rank once.  Only the rows whose double total
+    from (B) can still hold the smallest float32 potential are summed (the one-GPU path's rule, ``kpp_contender`` in
+    seeding.hip) -- usually one of the L.  Needs every rank's first row at a multiple of 4096
     (``dist.shard_bounds(..., align=POT_ALIGN)``); then the seeds are sklearn's bit for bit, as on one GPU.
     "f64": double sums (any row split).  Default: "openblas" when the split allows it.
     ``packed=False``: three collectives per centre (counts all-reduced, rows fetched by index, potentials as in (B)).
@@ -289,6 +295,9 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
     los_h = [int(v) for v in los.cpu()]
     if blas:
         nb_pad = max(int(((m & ~3) + POT_ALIGN - 1) // POT_ALIGN) for m in sizes_h)  # blocks of the longest piece
+        # a float32 chain of at most 1100 + (blocks of all pieces) additions of non-negative terms is within that many
+        # 2^-24 of the exact sum: a row whose double total exceeds the smallest by more than twice that cannot win
+        pot_eps = (1100.0 + nranks * nb_pad) / 8388608.0
 
     def fetch_rows(idx):
         """X[idx] for GLOBAL row indices idx [B, m] -> [B, m, D] on every rank (owners contribute, one all-reduce)."""
@@ -306,25 +315,24 @@ def kmeans_plusplus_sharded(X_local, row_offset, n_total, n_clusters, draws, gro
     def total_potentials(pot, rows=None):
         """(global potentials [B, m] in double, every rank's part [W, B, m], float32 potentials in OpenBLAS order or
         None); parts added in rank order.  ``rows`` [B, m, n_local]: this rank's piece of the candidate rows."""
-        payload = pot
-        if blas and rows is not None:
-            # [double part | the piece's block sums, zero padded | its tail sum]: one exchange for both
-            bs = ops.block_sums(rows)
-            m = rows.shape[1]
-            payload = torch.zeros((b, m, 1 + nb_pad + 1), dtype=torch.float64, device=dev)
-            payload[..., 0] = pot
-            payload[..., 1:bs.shape[2]] = bs[..., :-1].to(torch.float64)
-            payload[..., -1] = bs[..., -1].to(torch.float64)
-        every = gather(payload) if collective else payload[None]
-        parts = every[..., 0] if payload is not pot else every
+        parts = gather(pot) if collective else pot[None]
         tot = parts[0].clone()
         for r in range(1, parts.shape[0]):
             tot += parts[r]
         pot32 = None
-        if payload is not pot:
+        if blas and rows is not None:
+            m = rows.shape[1]
+            # rows that can still hold the smallest float32 potential (the same on every rank: from the gathered totals)
+            alive = tot * (1.0 - pot_eps) <= tot.min(dim=1, keepdim=True).values * (1.0 + pot_eps)
+            bs = ops.block_sums(rows, tot, pot_eps)
+            mine = torch.zeros((b, m, nb_pad + 1), dtype=torch.float32, device=dev)  # [block sums, zero padded | tail sum]
+            mine[..., :bs.shape[2] - 1] = bs[..., :-1]
+            mine[..., -1] = bs[..., -1]
+            every = gather(mine) if collective else mine[None]
             # the pieces' block sums side by side in rank order, then added one after the other in float
-            seq = every[..., 1:].to(torch.float32).permute(1, 2, 0, 3).reshape(b * rows.shape[1], -1)
-            pot32 = ops.combine(seq).view(b, rows.shape[1])
+            seq = every.permute(1, 2, 0, 3).reshape(b * m, -1)
+            pot32 = ops.combine(seq).view(b, m)
+            pot32 = torch.where(alive, pot32, torch.full_like(pot32, float("inf")))
         return tot, parts, pot32
 
     def first_potential(closest):

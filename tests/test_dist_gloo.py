@@ -358,9 +358,13 @@ def test_sharded_seeding_matches_oracle(world, packed, tmp_path):
 class BlasSeedOps(NumpySeedOps):
     """NumpySeedOps plus the piecewise OpenBLAS-order sums (oracle.c's restatements of sgemv_t / sdot)."""
 
-    def block_sums(self, rows):
+    def block_sums(self, rows, pot64=None, eps=0.0):
         r = rows.numpy()
-        return torch.from_numpy(np.stack([O.sgemv_t_block_sums(r[i]) for i in range(r.shape[0])]))
+        out = np.stack([O.sgemv_t_block_sums(r[i]) for i in range(r.shape[0])])
+        if pot64 is not None:  # rows outside the margin are not summed (zeros), like the device entry
+            p = pot64.numpy()
+            out[~(p * (1.0 - eps) <= p.min(axis=1, keepdims=True) * (1.0 + eps))] = 0.0
+        return torch.from_numpy(out)
 
     def combine(self, parts):
         return torch.from_numpy(O.combine_block_sums(parts.numpy()))

@@ -517,6 +517,15 @@ def test_blas_order_piecewise_entries(n, gpu_device):
     if n:
         for i in range(b):
             assert np.array_equal(comb[i], O.rowsums_blas_order(rows[i]))
+    if n >= 64:  # with the rows' double totals given, a row that cannot hold the smallest sum is not walked
+        rows2 = rows.copy()
+        rows2[:, 1, :] *= 2.0
+        rows2[:, 2, :] = rows2[:, 0, ::-1]  # the same total up to rounding: both stay in
+        p64 = rows2.astype(np.float64).sum(axis=2)
+        part_f = ops.block_sums(dev(rows2, gpu_device), dev(p64, gpu_device), 1e-3).cpu().numpy()
+        for i in range(b):
+            want = O.sgemv_t_block_sums(rows2[i])
+            assert np.array_equal(part_f[i, [0, 2]], want[[0, 2]]) and not part_f[i, 1, :-1].any()
     # sdot: the first restart's rows cut into three pieces at multiples of 64 (what a 4096-aligned split gives)
     x = np.ascontiguousarray(rows[:, 0, :])
     n64 = n & -64

@@ -23,14 +23,14 @@ X = make_encodings(n, d, k_full, seed=1000, device=dev)
 K.sub_rowvec_(X, (K.col_sums(X) / n).to(torch.float32))
 rs = np.random.RandomState(0)
 draws = [seeding.draw(rs, n, k_full) for _ in range(b)]
-for k in (5, 33):
+for order, k in (("f64", 5), ("f64", 33), ("openblas", 5), ("openblas", 33)):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    c, i = seeding.kmeans_plusplus_sharded(X, 0, n, k, draws)
+    c, i = seeding.kmeans_plusplus_sharded(X, 0, n, k, draws, pot_order=order)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if k == 33:
         flop = 2.0 * n * d * b * 8 * (k - 1)
-        print(json.dumps({"n_local": n, "d": d, "restarts": b, "local_trials": 8, "centres": k, "s": dt,
+        print(json.dumps({"n_local": n, "d": d, "restarts": b, "local_trials": 8, "centres": k, "pot_order": order, "s": dt,
                           "ms_per_step": dt / (k - 1) * 1e3, "fp64_TFLOP/s_incl_overheads": flop / dt / 1e12,
                           "full_seeding_of_1024_centres_s": dt / (k - 1) * 1023}))
