@@ -130,16 +130,155 @@ __global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X
         have_cur = true;
     }
     __syncthreads();
-    // flush: LDS element (row, e*dq + c) is column 4c+e
-    for (int idx = tid; idx < kn * d; idx += nthreads) {
-        const double v = (double)acc[idx];
-        if (v != 0.0) {
-            const int row = idx / d, off = idx % d;
-            const int e = off / dq, c = off % dq;
-            atomicAdd(&sums[(size_t)(k0 + row) * d + 4 * c + e], v);
+    // flush in the order of the global array (consecutive lanes add to consecutive doubles; LDS element
+    // (row, e*dq + c) is column 4c+e), every row chunk of a cluster range starting at a different place so that the
+    // workgroups of a range, which finish together, do not queue up on the same addresses
+    {
+        const int kd = kn * d;
+        const int start = (int)((int64_t)blockIdx.x * kd / gridDim.x);
+        double *out = sums + (size_t)k0 * d;
+        for (int j = tid; j < kd; j += nthreads) {
+            int gidx = j + start;
+            if (gidx >= kd) gidx -= kd;
+            const int row = gidx / d, col = gidx % d;
+            const double v = (double)acc[(size_t)row * d + (col & 3) * dq + (col >> 2)];
+            if (v != 0.0) atomicAdd(&out[gidx], v);
         }
     }
     for (int idx = tid; idx < kn; idx += nthreads)
         if (cnt[idx] != 0) atomicAdd(&counts[k0 + idx], (double)cnt[idx]);
 }
 
+// The same sums when ONE workgroup holds all k clusters (k*d doubles fit the LDS: the reference's K = 200 at D = 96,
+// get_modality): every row of the chunk is added, so the ballot / bit-scan / shuffle that picks a range's rows out
+// of a batch of labels is not needed.  A wave takes batches of 64 consecutive rows; trip t of a batch adds rows
+// t*G*RPW .. +G*RPW-1, their labels come out of the batch's label register with v_readlane.
+// Where the time goes at 73 568 x 96, K = 200, 20 restarts in one launch (12 chunks x 20 = 240 workgroups, one per
+// CU; builds with parts switched off): 37 us with nothing but the label scan and the loop's instructions, +13 us
+// with the row loads, +20 us with the LDS adds (a ds_add_f64 instruction occupies the CU's LDS for 9 clocks
+// whatever its active lanes, tools/lds_atomic_rate), +22 us for the flush.
+template <int LPR, int G>
+__global__ __launch_bounds__(1024) void k_accumulate_all(const float *__restrict__ X, int64_t n, int d,
+                                                         const int32_t *__restrict__ labels, int k,
+                                                         int64_t rows_per_chunk, double *sums, double *counts,
+                                                         const int32_t *state, MtpBatchStride bs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];  // k*d doubles, then k ints
+    double *acc = reinterpret_cast<double *>(acc_raw);
+    // 1-D grid of chunks x restarts.  Workgroup i runs on XCD i % 8: the (chunk, restart) pairs are dealt out chunk-major
+    // in eight consecutive runs, one per XCD, so that the restarts that add the same rows share an L2 -- the rows come
+    // from HBM / the memory-side cache once per XCD instead of once per restart.
+    int chunk;
+    {
+        const int total = gridDim.x, i = blockIdx.x, x = i & 7, q = total >> 3, r = total & 7;
+        const int w = x * q + min(x, r) + (i >> 3);
+        chunk = w / bs.batch;
+        const size_t b = w % bs.batch;  // restart
+        labels += b * bs.labels;
+        sums += b * bs.red;
+        counts += b * bs.red;
+        if (state != nullptr) state += b * bs.flags;
+    }
+    if (state != nullptr && *state != MTP_STATE_RUNNING) return;
+    int *cnt = reinterpret_cast<int *>(acc + (size_t)k * d);
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    for (int e = tid; e < k * d; e += nthreads) acc[e] = 0.0;
+    for (int e = tid; e < k; e += nthreads) cnt[e] = 0;
+    __syncthreads();
+
+    constexpr int RPW = 64 / LPR;   // rows per wave instruction
+    constexpr int TR = G * RPW;     // rows per trip
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int sub = lane / LPR, c0 = lane % LPR;
+    const int dq = d / 4;
+    const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
+    const int64_t r_end = min(n, r_begin + rows_per_chunk);
+    const int64_t stride = (int64_t)nwaves * 64;
+
+    float4 vc[G];
+    int rc[G];
+    int ic[G];  // the row, counted from the chunk's first (only rows wider than LPR*4 floats are fetched again)
+    bool have_cur = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        rc[g] = -1;
+        ic[g] = 0;
+        vc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto add_cur = [&]() {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (rc[g] >= 0) {
+                double *a = acc + (size_t)rc[g] * d + c0;
+                atomicAdd(a, (double)vc[g].x);
+                atomicAdd(a + dq, (double)vc[g].y);
+                atomicAdd(a + 2 * dq, (double)vc[g].z);
+                atomicAdd(a + 3 * dq, (double)vc[g].w);
+                for (int c = c0 + LPR; c < dq; c += LPR) {  // rows wider than LPR*4 floats
+                    const float4 w = reinterpret_cast<const float4 *>(X + (r_begin + ic[g]) * d)[c];
+                    atomicAdd(a + (c - c0), (double)w.x);
+                    atomicAdd(a + (c - c0) + dq, (double)w.y);
+                    atomicAdd(a + (c - c0) + 2 * dq, (double)w.z);
+                    atomicAdd(a + (c - c0) + 3 * dq, (double)w.w);
+                }
+            }
+        }
+    };
+
+    int64_t base = r_begin + (int64_t)wave * 64;
+    int lab_next = -1;
+    if (base + lane < r_end) lab_next = labels[base + lane];
+    for (; base < r_end; base += stride) {
+        int lab = lab_next;
+        lab_next = -1;  // the next batch's labels travel while this one's rows are added
+        if (base + stride + lane < r_end) lab_next = labels[base + stride + lane];
+        if ((unsigned)lab < (unsigned)k) atomicAdd(&cnt[lab], 1);
+        else lab = -1;  // beyond the chunk, or not a cluster: skipped
+        const int rows_here = (int)min((int64_t)64, r_end - base);
+        for (int t0 = 0; t0 < rows_here; t0 += TR) {
+            float4 vn[G];
+            int rn[G];
+            int in[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                int r = -1;
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) {
+                    const int rq = __builtin_amdgcn_readlane(lab, (t0 + g * RPW + q) & 63);
+                    if (q == sub) r = rq;
+                }
+                if (t0 + g * RPW + sub >= 64) r = -1;
+                rn[g] = (c0 < dq) ? r : -1;
+                in[g] = (int)(base - r_begin) + t0 + g * RPW + sub;
+                vn[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rn[g] >= 0) vn[g] = reinterpret_cast<const float4 *>(X + (r_begin + in[g]) * d)[c0];
+            }
+            if (have_cur) add_cur();
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                vc[g] = vn[g];
+                rc[g] = rn[g];
+                ic[g] = in[g];
+            }
+            have_cur = true;
+        }
+    }
+    if (have_cur) add_cur();
+    __syncthreads();
+    // flush in the order of the global array (consecutive lanes add to consecutive doubles; LDS element
+    // (row, e*dq + c) is column 4c+e), every chunk of a restart starting at a different place so that the workgroups
+    // of a restart, which finish together, do not queue up on the same addresses
+    {
+        const int kd = k * d;
+        const int chunks = gridDim.x / bs.batch;
+        const int start = (int)((int64_t)chunk * kd / (chunks > 0 ? chunks : 1));
+        for (int j = tid; j < kd; j += nthreads) {
+            int gidx = j + start;
+            if (gidx >= kd) gidx -= kd;
+            const int row = gidx / d, col = gidx % d;
+            const double v = acc[(size_t)row * d + (col & 3) * dq + (col >> 2)];
+            if (v != 0.0) atomicAdd(&sums[gidx], v);
+        }
+    }
+    for (int idx = tid; idx < k; idx += nthreads)
+        if (cnt[idx] != 0) atomicAdd(&counts[idx], (double)cnt[idx]);
+}

@@ -117,21 +117,6 @@ static int launch_assign_mfma_wpb(const float *X, int64_t n, const float *staged
     return MTP_OK;
 }
 
-static int device_cu_count(int *cus) {
-    static std::atomic<int> cached[MTP_MAX_DEVICES];
-    int dev = 0;
-    MTP_HIP(hipGetDevice(&dev));
-    const bool track = dev >= 0 && dev < MTP_MAX_DEVICES;
-    int c = track ? cached[dev].load(std::memory_order_acquire) : 0;
-    if (c == 0) {
-        MTP_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
-        if (c < 1) c = 1;
-        if (track) cached[dev].store(c, std::memory_order_release);
-    }
-    *cus = c;
-    return MTP_OK;
-}
-
 // The chip holds 2 workgroups of 8 waves per CU (68 KB of LDS, 128 VGPRs each): one ROUND = 2 x CUs workgroups.
 // Workgroups of equal cost run in lockstep, and the hardware spreads a last, partial round of up to CUs
 // workgroups one per CU but puts anything beyond that two per CU on some CUs: the launch time moves in steps
@@ -148,7 +133,7 @@ static int launch_assign_mfma(const float *X, int64_t n, const float *staged, in
                               double *n_changed, const int32_t *state, hipStream_t s, MtpBatchStride bs) {
     if (bs.batch != 1) return launch_assign_mfma_wpb<D, 8>(X, n, staged, k, labels, n_changed, state, s, bs);
     int cus = 0;
-    const int rc = device_cu_count(&cus);
+    const int rc = mtp_device_cu_count(&cus);
     if (rc != MTP_OK) return rc;
     const int64_t per_round = (int64_t)2 * cus * 256;  // points
     const int64_t n_main = n / per_round * per_round;

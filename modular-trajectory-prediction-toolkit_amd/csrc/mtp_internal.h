@@ -32,6 +32,22 @@ void mtp_set_error(const char *fmt, ...);
 
 constexpr int MTP_MAX_DEVICES = 64;  // per-device host state (function attributes, symbol addresses) is kept for this many
 
+// Compute units of the current device (cached per device).
+inline int mtp_device_cu_count(int *cus) {
+    static std::atomic<int> cached[MTP_MAX_DEVICES];
+    int dev = 0;
+    MTP_HIP(hipGetDevice(&dev));
+    const bool track = dev >= 0 && dev < MTP_MAX_DEVICES;
+    int c = track ? cached[dev].load(std::memory_order_acquire) : 0;
+    if (c == 0) {
+        MTP_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
+        if (c < 1) c = 1;
+        if (track) cached[dev].store(c, std::memory_order_release);
+    }
+    *cus = c;
+    return MTP_OK;
+}
+
 // hipFuncSetAttribute acts on the CURRENT device's function object: done once per device (not once per
 // process), safe from several host threads.  `func` in parentheses when it holds template commas.
 #define MTP_SET_MAX_LDS_ONCE(func, bytes)                                                                       \

@@ -47,9 +47,16 @@ int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *label
     const int n_ranges = (k + kr - 1) / kr;
     kr = (k + n_ranges - 1) / n_ranges;  // balance the ranges
     const size_t lds = (size_t)kr * d * 8 + (size_t)kr * 4;
-    // one workgroup per CU; a chunk must be worth its flush (kr*d doubles of atomics)
-    int64_t n_chunks = 256 / n_ranges;
-    if (bs.batch > 1) n_chunks = (n_chunks + bs.batch - 1) / bs.batch < 8 ? 8 : (n_chunks + bs.batch - 1) / bs.batch;
+    // One round of workgroups: a CU holds as many as fit its 160 KB of LDS (one at K = 200 / D = 96 and at the headline
+    // size), and the grid (chunks x ranges x restarts) must not exceed that -- 13 chunks x 20 restarts = 260
+    // workgroups on 256 CUs ran as two rounds.  A chunk must also be worth its flush (kr*d doubles of atomics).
+    int cus = 0;
+    if (const int rc = mtp_device_cu_count(&cus)) return rc;
+    int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t slots = (int64_t)cus * per_cu;
+    int64_t n_chunks = slots / ((int64_t)n_ranges * bs.batch);
     const int64_t min_rows = (int64_t)8 * kr + 1024;
     if (n_chunks > (n + min_rows - 1) / min_rows) n_chunks = (n + min_rows - 1) / min_rows;
     if (n_chunks < 1) n_chunks = 1;
@@ -63,6 +70,24 @@ int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *label
         hipLaunchKernelGGL((k_accumulate<LPR, 4, double, true>), grid, dim3(1024), lds, s, X, n, d, labels, k, kr, rows_per_chunk,    \
                            sums, counts, state, bs);                                                               \
     } while (0)
+#define MTP_ACC_LAUNCH_ALL(LPR)                                                                                    \
+    do {                                                                                                           \
+        MTP_SET_MAX_LDS_ONCE((&k_accumulate_all<LPR, 4>), ACC_LDS_BYTES + 1024);                                     \
+        hipLaunchKernelGGL((k_accumulate_all<LPR, 4>), dim3((unsigned)(n_chunks * bs.batch)), dim3(1024), lds, s, X, n, d,   \
+                           labels, k, rows_per_chunk, sums, counts, state, bs);                                    \
+    } while (0)
+    if (n_ranges == 1) {  // every row is added: no selection of a range's rows
+        if (dq <= 8)
+            MTP_ACC_LAUNCH_ALL(8);
+        else if (dq <= 16)
+            MTP_ACC_LAUNCH_ALL(16);
+        else if (dq <= 32)
+            MTP_ACC_LAUNCH_ALL(32);
+        else
+            MTP_ACC_LAUNCH_ALL(64);
+        MTP_LAUNCH_CHECK();
+        return MTP_OK;
+    }
     if (dq <= 8)
         MTP_ACC_LAUNCH(8);
     else if (dq <= 16)
@@ -72,6 +97,7 @@ int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *label
     else
         MTP_ACC_LAUNCH(64);
 #undef MTP_ACC_LAUNCH
+#undef MTP_ACC_LAUNCH_ALL
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
