@@ -71,27 +71,50 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
     const int j = lane & 31, h = lane >> 5;
     const int64_t pbase = ((int64_t)blockIdx.x * WPB + wave) * (32 * PT);
 
+    const int n_stages = (n_tiles + CTW - 1) / CTW;
+    const int wave_slot0 = wave * 64;
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    auto stage = [&](int t) {
+        const float *g = staged + (size_t)t * STAGE_F;
+        const unsigned l = smem_base + (unsigned)((t & 1) * STAGE_F * 4);
+        for (int s0 = wave_slot0; s0 < STAGE_SLOTS; s0 += 64 * WPB) {
+            if (s0 + lane < STAGE_SLOTS)
+                glds16(g + (size_t)(s0 + lane) * 4, __builtin_amdgcn_readfirstlane(l + (unsigned)s0 * 16));
+        }
+    };
+    stage(0);  // the first centroid stage travels while the points are fetched
+
     // ---- B operands: this wave's points, k = 2s + h for step s, kept in registers ----
+    // Lanes j and j + 32 hold the same point.  Lane half h fetches the 16-byte slots 2m + h of the row -- each byte of
+    // the row once per wave, D/8 loads per lane, in one or two round trips -- and the halves then trade what the other
+    // needs with v_permlane32_swap: half 0 ends up with the even features, half 1 with the odd ones.  (Every lane
+    // fetching the whole row and dropping half of it took D/4 loads in groups of 8: three to four dependent round
+    // trips before the first MFMA, a fifth of a workgroup's life at the reference's K = 200.)
+    constexpr int SLOTS = D / 8;                    // slots per lane
+    constexpr int SG = SLOTS <= 12 ? SLOTS : 8;     // in flight at once (raw registers: 4 per slot)
+    static_assert(SLOTS % SG == 0, "slot groups");
     float xr[PT][D / 2];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         int64_t row = pbase + pt * 32 + j;
         if (row >= n) row = n - 1;  // tail rows are computed and discarded
         const float4 *xp = reinterpret_cast<const float4 *>(X + row * D);
-        // groups of LG 16-byte loads in flight; half of every load is dropped by the select.
-        // pin2 keeps the selects next to their loads: sunk below the first branch they made the
-        // compiler hold all D raw values at once and spill.
 #pragma unroll
-        for (int q0 = 0; q0 < D / 4; q0 += LG) {
-            float4 v[LG];
+        for (int m0 = 0; m0 < SLOTS; m0 += SG) {
+            float4 v[SG];
 #pragma unroll
-            for (int g = 0; g < LG; ++g) v[g] = xp[q0 + g];
+            for (int g = 0; g < SG; ++g) v[g] = xp[2 * (m0 + g) + h];
 #pragma unroll
-            for (int g = 0; g < LG; ++g) {
-                const int q = q0 + g;
-                xr[pt][2 * q] = h ? v[g].y : v[g].x;
-                xr[pt][2 * q + 1] = h ? v[g].w : v[g].z;
-                pin2(xr[pt][2 * q], xr[pt][2 * q + 1]);
+            for (int g = 0; g < SG; ++g) {
+                const int m = m0 + g;
+                // half 0 holds slot 2m (features 8m .. 8m+3), half 1 slot 2m+1 (8m+4 .. 8m+7).  swap(a, b): the upper
+                // lanes' a and the lower lanes' b change places.
+                const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g].x), __float_as_uint(v[g].y), false, false);
+                const auto zw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g].z), __float_as_uint(v[g].w), false, false);
+                xr[pt][4 * m + 0] = __uint_as_float(xy[0]);  // feature 8m + h
+                xr[pt][4 * m + 1] = __uint_as_float(zw[0]);  // 8m + 2 + h
+                xr[pt][4 * m + 2] = __uint_as_float(xy[1]);  // 8m + 4 + h
+                xr[pt][4 * m + 3] = __uint_as_float(zw[1]);  // 8m + 6 + h
             }
         }
     }
@@ -105,19 +128,6 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
         btile[pt] = 0;
     }
 
-    const int n_stages = (n_tiles + CTW - 1) / CTW;
-    const int wave_slot0 = wave * 64;
-    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
-    auto stage = [&](int t) {
-        const float *g = staged + (size_t)t * STAGE_F;
-        const unsigned l = smem_base + (unsigned)((t & 1) * STAGE_F * 4);
-        for (int s0 = wave_slot0; s0 < STAGE_SLOTS; s0 += 64 * WPB) {
-            if (s0 + lane < STAGE_SLOTS)
-                glds16(g + (size_t)(s0 + lane) * 4, __builtin_amdgcn_readfirstlane(l + (unsigned)s0 * 16));
-        }
-    };
-
-    stage(0);
     for (int t = 0; t < n_stages; ++t) {
         dma_wait();       // this wave's share of stage t has landed ...
         __syncthreads();  // ... and so has everyone else's; all waves are done with the other buffer
