@@ -457,6 +457,11 @@ def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_it
     from . import seeding
     rank, ws = world()
     collective = ws > 1 or (force_collectives and dist.is_initialized())
+    if collective:  # decided from gathered sizes, so that every rank raises (a rank that stopped alone would hang the others)
+        sizes = all_gather_cat(torch.tensor([X_local.shape[0]], dtype=torch.int64, device=X_local.device), ws, group)
+        if int(sizes.min()) == 0:
+            raise ValueError(f"kmeans_fit_sharded: every rank must hold at least one row, got {sizes.tolist()} "
+                             "(shard_bounds(..., align=a) leaves ranks empty when n_total < world_size * a)")
     if stats is None:
         from . import kernels as K
         col_sums, col_sqdev, sub_rowvec_ = K.col_sums, K.col_sqdev, K.sub_rowvec_

@@ -423,6 +423,23 @@ def test_sharded_seeding_in_openblas_order(world, n, tmp_path):
             assert np.array_equal(p["centers"][r], want[r][0])
 
 
+def _empty_rank_worker(rank, world, port):
+    sys.path[:0] = [PKG_DIR]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pccs_accel import dist as pdist
+    X = torch.zeros((5 if rank == 0 else 0, 16), dtype=torch.float32)
+    with pytest.raises(ValueError, match="at least one row"):  # on every rank, before any kernel or further collective
+        pdist.kmeans_fit_sharded(X, 5, row_offset=0 if rank == 0 else 5, n_clusters=2, n_init=1, random_state=0,
+                                 stats=(None, None, None))
+    dist.destroy_process_group()
+
+
+def test_fit_with_an_empty_rank_is_refused_everywhere():
+    mp.spawn(_empty_rank_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
 def _fit_worker(rank, world, port, out_dir, numpy_stats=False):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
