@@ -8,8 +8,8 @@ oracle (this is test code; the product's DeviceOps is what runs on a GPU).  Ever
 must reproduce the oracle's single-process ``kmeans_single_lloyd``.
 """
 import os
-import socket
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -153,9 +153,7 @@ def _oracle(which, Xc, C0, max_iter, tol):
 
 def _worker(rank, world, port, which, check_every, out_dir, fixed_steps=0, max_iter=300):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from pccs_accel import dist as pdist
     Xc, C0, tol = _case(which)
     lo, hi = pdist.shard_bounds(Xc.shape[0], rank, world)
@@ -173,11 +171,12 @@ def _worker(rank, world, port, which, check_every, out_dir, fixed_steps=0, max_i
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous for one spawn: the path of a file for torch.distributed's FileStore (handed to the workers as
+    ``port``).  A TCP port picked here could be taken by someone else before rank 0 binds it (seen on a shared box)."""
+    fd, path = tempfile.mkstemp(prefix="mtp_rdv_")
+    os.close(fd)
+    os.unlink(path)
+    return path
 
 
 @pytest.mark.parametrize("which", ["plain", "relocate", "many_empty"])
@@ -245,9 +244,7 @@ def test_lagged_flag_checks_stop_at_max_iter(which, tmp_path):
 
 def _eval_worker(rank, world, port, out_dir):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from pccs_accel import dist as pdist
     pred, gt = _eval_case()
     lo, hi = pdist.shard_bounds(pred.shape[0], rank, world)
@@ -321,9 +318,7 @@ def _seed_case():
 
 def _seed_worker(rank, world, port, out_dir, packed=True):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from pccs_accel import dist as pdist
     from pccs_accel import seeding
     Xc = _seed_case()
@@ -385,9 +380,7 @@ def _blas_seed_case(n):
 
 def _blas_seed_worker(rank, world, port, out_dir, n):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from pccs_accel import dist as pdist
     from pccs_accel import seeding
     Xc = _blas_seed_case(n)
@@ -425,9 +418,7 @@ def test_sharded_seeding_in_openblas_order(world, n, tmp_path):
 
 def _empty_rank_worker(rank, world, port):
     sys.path[:0] = [PKG_DIR]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from pccs_accel import dist as pdist
     X = torch.zeros((5 if rank == 0 else 0, 16), dtype=torch.float32)
     with pytest.raises(ValueError, match="at least one row"):  # on every rank, before any kernel or further collective
@@ -442,9 +433,7 @@ def test_fit_with_an_empty_rank_is_refused_everywhere():
 
 def _fit_worker(rank, world, port, out_dir, numpy_stats=False):
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from pccs_accel import dist as pdist
     X = _fit_case()
     lo, hi = pdist.shard_bounds(X.shape[0], rank, world)

@@ -5,8 +5,8 @@ in test_gpu_parity.py): identical labels and n_iter, centres to 1e-6 -- the doub
 sums make the trajectory independent of how the points are split.
 """
 import os
-import socket
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -42,10 +42,8 @@ def _worker(rank, world, port, which, check_every, out_dir, lagged_steps=0):
     import faulthandler
     faulthandler.dump_traceback_later(60, exit=True)  # a stuck rank names its line and ends the test
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from pccs_accel import dist as pdist
     X, C0 = _case(which)
     dev = torch.device("cuda:0")
@@ -59,11 +57,12 @@ def _worker(rank, world, port, which, check_every, out_dir, lagged_steps=0):
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous for one spawn: the path of a file for torch.distributed's FileStore (handed to the workers as
+    ``port``).  A TCP port picked here could be taken by someone else before rank 0 binds it (seen on a shared box)."""
+    fd, path = tempfile.mkstemp(prefix="mtp_rdv_")
+    os.close(fd)
+    os.unlink(path)
+    return path
 
 
 @pytest.mark.parametrize("which", ["plain", "relocate", "many_empty"])
@@ -90,12 +89,10 @@ def _rccl_worker(rank, port, which, out_dir):
     import faulthandler
     faulthandler.dump_traceback_later(90, exit=True)
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "tests", "golden")]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", init_method=f"file://{port}", rank=0, world_size=1, device_id=dev)
     from pccs_accel import dist as pdist
     X, C0 = _case(which)
     fit = pdist.kmeans_fit_sharded(torch.from_numpy(X).to(dev), X.shape[0], torch.from_numpy(C0).to(dev),
@@ -126,12 +123,10 @@ def _native_worker(rank, port, which, out_dir):
     import faulthandler
     faulthandler.dump_traceback_later(90, exit=True)
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "tests", "golden")]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", init_method=f"file://{port}", rank=0, world_size=1, device_id=dev)
     from pccs_accel import dist as pdist
     X, C0 = _case(which)
     comm = pdist.RcclComm(dev)
@@ -177,15 +172,13 @@ def _pp_worker(rank, world, port, backend, out_dir, n=6007, order="f64"):
     import faulthandler
     faulthandler.dump_traceback_later(120, exit=True)
     sys.path[:0] = [PKG_DIR, os.path.join(ROOT, "tests", "golden")]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", init_method=f"file://{port}", rank=rank, world_size=world, device_id=dev)
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from pccs_accel import dist as pdist
     from pccs_accel import seeding
     X = _pp_case(n)
