@@ -84,6 +84,19 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
     };
     stage(0);  // the first centroid stage travels while the points are fetched
 
+    // The labels of the iteration before (only compared at the very end) are requested now, so that the workgroup does
+    // not end on a dependent load; inline asm because the compiler would sink a plain load to its use.
+    int old_lab[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        old_lab[pt] = 0;
+        if (n_changed != nullptr) {
+            int64_t row = pbase + pt * 32 + j;
+            if (row >= n) row = n - 1;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(old_lab[pt]) : "v"(labels + row) : "memory");
+        }
+    }
+
     // ---- B operands: this wave's points, k = 2s + h for step s, kept in registers ----
     // Lanes j and j + 32 hold the same point.  Lane half h fetches the 16-byte slots 2m + h of the row -- each byte of
     // the row once per wave, D/8 loads per lane, in one or two round trips -- and the halves then trade what the other
@@ -223,10 +236,10 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
         const bool take = (ob < best[pt]) || (ob == best[pt] && oi < mine);
         const int lab = take ? oi : mine;
         const int64_t row = pbase + pt * 32 + j;
+        if (n_changed != nullptr) asm volatile("s_waitcnt vmcnt(0)" : "+v"(old_lab[pt])::"memory");
         if (h == 0 && row < n) {
-            const int old = labels[row];
             labels[row] = lab;
-            changed += (old != lab);
+            changed += (old_lab[pt] != lab);
         }
     }
     if (n_changed != nullptr) {

@@ -58,6 +58,23 @@ void launch_v(const float *X, int64_t n, const float *staged, int k, int32_t *la
     CK(hipGetLastError());
 }
 
+// the product's batched launch as the fit issues it: per-restart loop state read first, changed labels counted
+static double *g_changed = nullptr;  // [batch] (stride g_bs.red)
+static int32_t *g_state = nullptr;   // [batch] (stride g_bs.flags), all RUNNING
+template <int D, bool STATE = true, bool CHANGED = true>
+void launch_flags(const float *X, int64_t n, const float *staged, int k, int32_t *labels, hipStream_t s) {
+    const size_t lds = 2 * (size_t)2 * mtp_tile_floats(D) * sizeof(float);
+    static bool set = false;
+    if (!set) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign_mfma<D, 1, 2, 8, 4, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        set = true;
+    }
+    hipLaunchKernelGGL((k_assign_mfma<D, 1, 2, 8, 4, true>), dim3((unsigned)((n + 255) / 256), g_bs.batch), dim3(512), lds, s, X, n,
+                       staged, (k + 31) / 32, labels, CHANGED ? g_changed : nullptr, STATE ? g_state : nullptr, g_bs);
+    CK(hipGetLastError());
+}
+
 template <int D, int WPB, int WPS, int LG = 8>
 void launch_pipe(const float *X, int64_t n, const float *staged, int k, int32_t *labels, hipStream_t s) {
     const size_t lds = 2 * (size_t)2 * mtp_tile_floats(D) * sizeof(float) + (size_t)mtp_n_tiles(k) * 32 * sizeof(float);
@@ -147,11 +164,23 @@ int run(int64_t n, int k, const char *filter, int batch) {
     g_bs.batch = batch;
     g_bs.staged = image;
     g_bs.labels = (size_t)n;
+    g_bs.red = 512;    // doubles between the restarts' changed counters
+    g_bs.flags = 512;  // int32s between the restarts' loop states
+    CK(hipMalloc(&g_changed, (size_t)batch * 512 * 8));
+    CK(hipMalloc(&g_state, (size_t)batch * 512 * 4));
+    CK(hipMemset(g_changed, 0, (size_t)batch * 512 * 8));
+    {
+        std::vector<int32_t> st((size_t)batch * 512, MTP_STATE_RUNNING);
+        CK(hipMemcpy(g_state, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+    }
     CK(hipDeviceSynchronize());
 
     std::vector<Variant> vs = {
         {"PT1 CTW2 WPB8 WPS4 (one launch)", launch_v<D, 1, 2, 8, 4, true>, true},
         {"SPLIT rounds + tail (product)", launch_split<D>, true},
+        {"PT1 CTW2 WPB8 WPS4 with loop state + changed count", launch_flags<D>, true},
+        {"PT1 CTW2 WPB8 WPS4 with loop state only", launch_flags<D, true, false>, true},
+        {"PT1 CTW2 WPB8 WPS4 with changed count only", launch_flags<D, false, true>, true},
         {"QUEUE small 0", launch_queue<D, 4, 0>, true},
         {"QUEUE small 1/wg", launch_queue<D, 4, 1>, true},
         {"QUEUE small 2/wg", launch_queue<D, 4, 2>, true},
