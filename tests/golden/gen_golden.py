@@ -338,6 +338,11 @@ G14_CASES = [
     # name, data seed, n, d, k_true, K, spread, noise, np.random.seed
     ("g14_fit_eth_n73568_k200", 141, 73568, 96, 120, 200, 1800, 420, 7),
     ("g14_fit_sdd_n17970_k400", 142, 17970, 96, 150, 400, 1800, 420, 8),
+    # the other four leave-one-out splits of ETH/UCY (N_train hotel 76 646, univ 30 128, zara1 74 084, zara2 66 976)
+    ("g14_fit_hotel_n76646_k200", 143, 76646, 96, 120, 200, 1800, 420, 9),
+    ("g14_fit_univ_n30128_k200", 144, 30128, 96, 120, 200, 1800, 420, 10),
+    ("g14_fit_zara1_n74084_k200", 145, 74084, 96, 120, 200, 1800, 420, 11),
+    ("g14_fit_zara2_n66976_k200", 146, 66976, 96, 120, 200, 1800, 420, 12),
 ]
 
 
@@ -412,10 +417,11 @@ def gen_g14(utility, only=None):
 if __name__ == "__main__":
     warnings.simplefilter("error")  # a ConvergenceWarning here means a bad fixture
     utility, metrics = _import_ref("PCCSNet")
-    only = sys.argv[1:]
+    only = [a for a in sys.argv[1:] if not a.startswith("g14_")]
+    g14_only = [a for a in sys.argv[1:] if a.startswith("g14_")]  # e.g. `gen_golden.py g14 g14_fit_univ_n30128_k200`
     jobs = dict(g1=lambda: gen_g1(utility), g2=lambda: gen_g2(utility), g45=gen_g4_g5,
                 g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, g13=gen_g13,
-                g14=lambda: gen_g14(utility))
+                g14=lambda: gen_g14(utility, g14_only or None))
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

@@ -97,7 +97,8 @@ def _g14_inputs(g):
     return X
 
 
-@pytest.mark.parametrize("name", ["g14_fit_sdd_n17970_k400", "g14_fit_eth_n73568_k200"])
+@pytest.mark.parametrize("name", ["g14_fit_sdd_n17970_k400", "g14_fit_eth_n73568_k200", "g14_fit_hotel_n76646_k200",
+                                  "g14_fit_univ_n30128_k200", "g14_fit_zara1_n74084_k200", "g14_fit_zara2_n66976_k200"])
 def test_seeded_fit_at_reference_size(name, gpu_device):
     from pccs_accel import clustering
     g = load_golden(name)
