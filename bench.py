@@ -24,7 +24,7 @@ The JSON line also carries
 and, as extra keys, the M-step kernel's HBM rate, the second half of the metric -- best-of-K ADE/FDE
 trajectories/s on configs[4] (1M agents x K=100 x T=12) with the reference's per-agent torch loop and
 NumPy loop as its CPU baselines -- and reference_configs: the whole KMeans(K, n_init=20) fit at the
-reference's own sizes (configs[0..2]: eth N=73 568 / K=200, SDD N=17 970 / K=400) with its dominant
+reference's own sizes (configs[0..2]: the five ETH/UCY splits N=30 128 .. 76 646 / K=200, SDD N=17 970 / K=400) with its dominant
 kernel's roofline.
 """
 import argparse
@@ -244,7 +244,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
-    ap.add_argument("--no-ref-configs", action="store_true", help="skip the reference-sized configs (eth, SDD)")
+    ap.add_argument("--no-ref-configs", action="store_true", help="skip the reference-sized configs (the five ETH/UCY splits, SDD)")
     ap.add_argument("--loop", choices=["library", "python"], default="library",
                     help="library: the K timed iterations are ONE call of mtp_lloyd_sharded_f32 (loop, RCCL all-reduce and "
                          "event timing inside libmtp_accel.so); python: the step-level driver ShardedLloyd.run_fixed "
@@ -555,8 +555,13 @@ def main():
     if world == 1 and not args.no_ref_configs:
         del X
         torch.cuda.empty_cache()
+        # BASELINE configs 0-2: the five ETH/UCY leave-one-out splits (train / val sizes of SURVEY.md 8) and SDD
         out["reference_configs"] = {
             "eth": reference_config("eth split", 73_568, 200, 2_614, 10, device, not args.no_cpu),
+            "hotel": reference_config("hotel split", 76_646, 200, 1_075, 11, device, not args.no_cpu),
+            "univ": reference_config("univ split", 30_128, 200, 24_334, 12, device, not args.no_cpu),
+            "zara1": reference_config("zara1 split", 74_084, 200, 2_356, 13, device, not args.no_cpu),
+            "zara2": reference_config("zara2 split", 66_976, 200, 5_910, 14, device, not args.no_cpu),
             "sdd": reference_config("SDD", 17_970, 400, 2_829, 20, device, not args.no_cpu)}
 
     if rank == 0:
