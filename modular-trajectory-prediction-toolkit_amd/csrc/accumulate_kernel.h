@@ -213,12 +213,14 @@ __global__ __launch_bounds__(1024) void k_accumulate_all(const float *__restrict
                 atomicAdd(a + dq, (double)vc[g].y);
                 atomicAdd(a + 2 * dq, (double)vc[g].z);
                 atomicAdd(a + 3 * dq, (double)vc[g].w);
-                for (int c = c0 + LPR; c < dq; c += LPR) {  // rows wider than LPR*4 floats
-                    const float4 w = reinterpret_cast<const float4 *>(X + (r_begin + ic[g]) * d)[c];
-                    atomicAdd(a + (c - c0), (double)w.x);
-                    atomicAdd(a + (c - c0) + dq, (double)w.y);
-                    atomicAdd(a + (c - c0) + 2 * dq, (double)w.z);
-                    atomicAdd(a + (c - c0) + 3 * dq, (double)w.w);
+                if constexpr (LPR == 64) {  // rows wider than LPR*4 floats (the launcher picks LPR >= d/4 up to 64)
+                    for (int c = c0 + LPR; c < dq; c += LPR) {
+                        const float4 w = reinterpret_cast<const float4 *>(X + (r_begin + ic[g]) * d)[c];
+                        atomicAdd(a + (c - c0), (double)w.x);
+                        atomicAdd(a + (c - c0) + dq, (double)w.y);
+                        atomicAdd(a + (c - c0) + 2 * dq, (double)w.z);
+                        atomicAdd(a + (c - c0) + 3 * dq, (double)w.w);
+                    }
                 }
             }
         }
