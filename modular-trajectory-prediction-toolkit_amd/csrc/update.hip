@@ -454,16 +454,17 @@ extern "C" int mtp_col_sqdev_f32(const float *X, int64_t n, int d, const double 
 // oracle.c's restatement), and X.mean(axis=0) / np.var(X, axis=0) are built on it (numpy/_core/_methods.py
 // _mean, _var): a sum in another order moves the column means by an ulp, the centred points with them, and
 // a few points per 7e4 change cluster.  One chain of n dependent float additions per column: the kernel is
-// bound by the addition latency (~n x 6 clocks), not by memory.  A workgroup owns 16 columns; all 256
-// threads bring tiles of 512 rows x 16 columns to LDS (column-major, double buffered, the next tile's loads are
-// in flight while this one is walked), 16 lanes walk them with 16-byte LDS reads.
+// bound by the addition latency (~n x 6 clocks), not by memory.  A workgroup owns 16 columns; its first 256
+// threads bring tiles of 512 rows x 16 columns to LDS (column-major, triple buffered, the next tile's loads are
+// in flight while this one is walked), 16 lanes of a FIFTH wave walk them with 16-byte LDS reads -- a wave that
+// does nothing else, so that the chain never waits behind the wave's share of the loads and deposits.
 // SQ: the summand is (x - center[c])^2 formed in float like NumPy's x = arr - arrmean; x * x.
 // ------------------------------------------------------------------------------------------
 constexpr int SEQ_COLS = 16, SEQ_ROWS = 512, SEQ_PITCH = SEQ_ROWS + 4;  // LDS tile: [column][row], rows padded
 
 // VEC: d % 4 == 0, a thread loads 16 bytes (4 columns of one row) at a time; else one float.
 template <bool SQ, bool VEC>
-__global__ __launch_bounds__(256) void k_col_seqsum(const float *__restrict__ X, int64_t n, int d,
+__global__ __launch_bounds__(320) void k_col_seqsum(const float *__restrict__ X, int64_t n, int d,
                                                     const float *__restrict__ center, const float *__restrict__ init,
                                                     float *out) {
     // three tile buffers: one being walked, one complete, one being filled; the global loads of a tile are
@@ -484,7 +485,10 @@ __global__ __launch_bounds__(256) void k_col_seqsum(const float *__restrict__ X,
             mu[0] = center[c0 + lc];
         }
     }
+    const bool loader = tid < 256;  // threads 256 .. 271 walk, 272 .. 319 only keep the barriers
+    const int wl = tid - 256;
     auto load = [&](int64_t r0, float(&v)[PER]) {
+        if (!loader) return;
         if (VEC) {
 #pragma unroll
             for (int e = 0; e < PER / 4; ++e) {
@@ -504,6 +508,7 @@ __global__ __launch_bounds__(256) void k_col_seqsum(const float *__restrict__ X,
     // the summands are formed by the loading threads (all 256), so that the walk is additions only;
     // rows past the end are not walked
     auto store = [&](int buf, const float(&v)[PER]) {
+        if (!loader) return;
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             float w = v[e];
@@ -518,11 +523,11 @@ __global__ __launch_bounds__(256) void k_col_seqsum(const float *__restrict__ X,
         }
     };
     // init: the chain continues from another block of rows (row-sharded points: the rank before this one)
-    float acc = (init != nullptr && tid < SEQ_COLS && c0 + tid < d) ? init[c0 + tid] : 0.f;
+    float acc = (init != nullptr && wl >= 0 && wl < SEQ_COLS && c0 + wl < d) ? init[c0 + wl] : 0.f;
     auto walk = [&](int buf, int64_t r0) {
-        if (tid >= SEQ_COLS) return;
+        if (wl < 0 || wl >= SEQ_COLS) return;
         const int rows = (int)((n - r0) < SEQ_ROWS ? (n - r0) : SEQ_ROWS);
-        const float *t = tile[buf] + tid * SEQ_PITCH;
+        const float *t = tile[buf] + wl * SEQ_PITCH;
         int r = 0;
         for (; r + 32 <= rows; r += 32) {
             float4 w[8];
@@ -559,13 +564,13 @@ __global__ __launch_bounds__(256) void k_col_seqsum(const float *__restrict__ X,
         walk((int)((t + 1) % 3), (t + 1) * SEQ_ROWS);
         __syncthreads();
     }
-    if (tid < SEQ_COLS && c0 + tid < d) out[c0 + tid] = acc;
+    if (wl >= 0 && wl < SEQ_COLS && c0 + wl < d) out[c0 + wl] = acc;
 }
 
 extern "C" int mtp_col_seqsum_carry_f32(const float *X, int64_t n, int d, const float *center, const float *init,
                                         float *out, void *stream) {
     MTP_REQUIRE((X || n == 0) && out && n >= 0 && d >= 1, "mtp_col_seqsum: bad arguments");
-    const dim3 grid((unsigned)((d + SEQ_COLS - 1) / SEQ_COLS)), block(256);
+    const dim3 grid((unsigned)((d + SEQ_COLS - 1) / SEQ_COLS)), block(320);
     hipStream_t s = mtp_stream(stream);
     const bool vec = d % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     if (center != nullptr) {
