@@ -1,5 +1,6 @@
 """The seeded whole fit at the reference's real sizes (BASELINE configs 0-2): ``np.random.seed(s);
-cluster_data(X, K)`` = ``KMeans(K, n_init=20).fit`` on N=73 568 / K=200 (eth split) and N=17 970 / K=400
+cluster_data(X, K)`` = ``KMeans(K, n_init=20).fit`` on the train-set sizes of the five ETH/UCY leave-one-out
+splits (N=73 568 eth, 76 646 hotel, 30 128 univ, 74 084 zara1, 66 976 zara2; K=200) and on N=17 970 / K=400
 (SDD), against fixture G14, which tests/golden/gen_golden.py recorded from the reference itself with
 sklearn's per-restart functions wrapped.
 
