@@ -171,3 +171,25 @@ def test_seeded_fit_at_reference_size(name, gpu_device):
         assert rel.max() <= max(3 * own_gap, 1e-3)
     sizes = np.bincount(final, minlength=K)
     assert int(np.abs(sizes - g["sizes"]).sum()) <= 2 * max(4 * own_spread, n // 500)
+
+
+@pytest.mark.parametrize("name", ["g14_fit_sdd_n17970_k400", "g14_fit_eth_n73568_k200"])
+def test_get_modality_at_reference_size(name, gpu_device):
+    """get_modality (PCCSNet/utils/utility.py:98-105) on the reference-sized encodings with sklearn's recorded final
+    labels: the segmented sums (one workgroup holds all K clusters at these sizes -- k_accumulate_all -- for K = 200;
+    two cluster ranges for K = 400) against the oracle's double sums, the means against the oracle's restatement of
+    the reference's per-cluster torch.mean."""
+    from pccs_accel import kernels as K
+    from pccs_accel.utils.utility import get_modality
+    g = load_golden(name)
+    X = _g14_inputs(g)
+    k = int(g["K"])
+    labels = g["labels"].astype(np.int32)
+    Xd = torch.from_numpy(X).to(gpu_device)
+    sums, counts = K.centroid_sums(Xd, torch.from_numpy(labels).to(gpu_device), k)
+    ws, wc = O.accumulate_f64(X, labels, k)
+    assert np.array_equal(counts.cpu().numpy(), wc) and np.array_equal(wc.astype(np.int64), g["sizes"])
+    assert np.allclose(sums.cpu().numpy(), ws, rtol=1e-12, atol=1e-11)
+    mod = get_modality(torch.from_numpy(X), labels, k)
+    assert mod.dtype == torch.float32 and tuple(mod.shape) == (k, X.shape[1])
+    assert np.allclose(mod.numpy(), O.get_modality(X, labels, k), rtol=1e-6, atol=1e-7)
