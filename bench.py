@@ -257,6 +257,21 @@ def main():
                          "communicator anyway and issue every collective of the N > 1 path")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves.  The parent has
+    # not touched the GPU (importing torch does not); the ranks are fresh child processes of torch.distributed.run
+    # (never an exec of this process), rank 0's JSON line reaches stdout through the inherited descriptor, and the
+    # parent exits with the launcher's return code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: launching", " ".join(cmd), file=sys.stderr)
+        sys.exit(subprocess.run(cmd).returncode)
+
     # stdout carries ONE JSON line.  RCCL prints a version banner to the process's stdout when a communicator is
     # created: everything else written to fd 1 during the run goes to stderr, the JSON line to the real stdout.
     real_stdout = os.fdopen(os.dup(1), "w")
@@ -321,7 +336,10 @@ def main():
     TOL_NEVER = -1.0            # shift_tot <= tol never holds: no early exit inside the timed region
     MAX_IT = 1 << 30
     total_steps = args.warmup + args.steps
-    use_library = args.loop == "library" and args.backend != "gloo" and not args.one_device
+    # MTP_RCCL_LIB names another collective library for libmtp_accel.so to bind (tests/stub_nccl: shared memory, several
+    # processes on one GPU): with it the in-library loop can be rehearsed on one device, which RCCL itself refuses
+    stub_lib = os.environ.get("MTP_RCCL_LIB", "")
+    use_library = args.loop == "library" and ((args.backend != "gloo" and not args.one_device) or bool(stub_lib))
     loop_note = "library (mtp_lloyd_sharded_f32)"
     comm = None
     if use_library and collective:
@@ -361,9 +379,24 @@ def main():
         if it_t != args.steps:
             print(f"bench.py: the library loop ran {it_t} iterations, wanted {args.steps}; timing invalid", file=sys.stderr)
             sys.exit(3)
-        ms_assign, ms_accum, ms_rest = phase
+        ms_assign, ms_accum, ms_allreduce, ms_mstep = phase
+        ms_rest = ms_allreduce + ms_mstep
         noop = []
         sl = None
+        # SURVEY 8(d) item 4, "run-to-convergence count": the same points from the same C0 with sklearn's tolerance
+        # (tol = 1e-4 * mean column variance, _kmeans.py:279-287) to the end, outside the timed region
+        sq = K.col_sqdev(X, torch.zeros(d, dtype=torch.float64, device=device))  # X is centred: deviations from 0
+        if collective:
+            allreduce(sq)
+        tol_abs = float((sq / n).mean().item()) * 1e-4
+        barrier()
+        t0 = time.perf_counter()
+        lab_c, inertia_c, C_c, it_c = pdist.lloyd_sharded_native(comm, X, C0, lo, n, max_iter=300, tol_abs=tol_abs, check_every=8)
+        barrier()
+        convergence = {"n_iter": int(it_c), "total_ms": (time.perf_counter() - t0) * 1e3, "inertia": float(inertia_c),
+                       "tol_abs": tol_abs, "max_iter": 300,
+                       "note": "KMeans(init=C0, n_init=1, tol=1e-4) from the bench's fixed init on all N points, incl. the "
+                               "closing E-step and the inertia; flags checked every 8 iterations"}
         if comm is not None:
             comm.close()
     else:
@@ -415,6 +448,8 @@ def main():
         ms_assign = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         ms_accum = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
         ms_rest = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+        ms_allreduce = ms_mstep = None
+        convergence = lab_c = None
     ms_step = dt / args.steps * 1e3
     evals_per_s = float(n) * k * d * args.steps / dt
 
@@ -445,7 +480,10 @@ def main():
                    "n": n, "d": d, "k": k, "parallelism": f"points/{world}"},
         "iters_per_s": args.steps / dt, "loop": loop_note, "clusters_relocated": n_relocated,
         "noop_attempts_in_timed_region": len(noop),
-        "ms_breakdown": {"assign": ms_assign, "accumulate": ms_accum, "allreduce+mstep": ms_rest},
+        "ms_breakdown": {"assign": ms_assign, "accumulate": ms_accum, "allreduce+mstep": ms_rest,
+                         "allreduce": ms_allreduce, "mstep_finish": ms_mstep,
+                         "allreduce_pct_of_step": (100.0 * ms_allreduce / ms_step) if ms_allreduce is not None else None},
+        "convergence": convergence,
         "roofline": roofline, "roofline_update": roofline_update,
     }
 
@@ -538,6 +576,20 @@ def main():
         # parity gate run with the benchmark: the GPU E-step on the same sample and centres
         gl = K.assign(X[:ns].contiguous(), C0).cpu().numpy()
         out["parity"] = {"sample_points": int(ns), "label_mismatches_vs_cpu_oracle": int((gl != cpu_labels).sum())}
+        # centroid gate ("centroids vs get_modality <= 1e-5"): the modality means of the converged
+        # labels -- mtp_centroid_sums_f32 + mtp_cluster_means_f32 against the oracle's restatement of
+        # PCCSNet/utils/utility.py:98-105 on the same points and labels
+        if lab_c is not None:
+            import kmeans_oracle as O
+            lab_h = lab_c[:ns].cpu().numpy()
+            if len(np.unique(lab_h)) == k:
+                gm = K.cluster_means(*K.centroid_sums(X[:ns].contiguous(), lab_c[:ns].contiguous(), k))[0].cpu().numpy()
+                om = O.get_modality(Xs, lab_h, k)
+                scale = np.maximum(np.abs(om), 1e-3 * float(np.abs(om).max()))
+                out["parity"]["get_modality_max_rel_err_vs_cpu_oracle"] = float(np.max(np.abs(gm - om) / scale))
+                out["parity"]["get_modality_bar"] = 1e-5
+            else:
+                out["parity"]["get_modality_max_rel_err_vs_cpu_oracle"] = None  # a cluster without sample points
         cores = host_cores()
         sk8 = sklearn_baseline(Xs, C0h, k, d, min(8, cores))
         if sk8 is not None:

@@ -45,6 +45,7 @@ extern "C" {
 #define MTP_FLAG_STATE 0
 #define MTP_FLAG_N_ITER 1
 #define MTP_FLAG_N_EMPTY 2
+#define MTP_FLAG_PEER_FAILED 7 /* mtp_lloyd_sharded_f32: a rank reported a failed far-point search */
 #define MTP_FLAG_WORDS 8
 
 const char *mtp_last_error(void);
@@ -181,9 +182,20 @@ int mtp_far_points_f32(const float *X, int64_t n, int d, const float *C_old, con
                        int64_t idx_offset, float *far_val, int64_t *far_idx, int32_t *far_lab,
                        float *far_rows, float *dist_scratch, void *stream);
 /* Apply: the i-th empty cluster (ascending id) takes far_rows[i]; its old cluster loses it.
+ * Only the clusters that are empty when the call starts are served (sklearn fixes empty_clusters before its
+ * loop, :176): a cluster that loses its only member to an earlier relocation of the same call is not.
  * Skipped entirely when far_val[0] == 0 (more clusters than distinct points). */
 int mtp_apply_relocation_f32(double *red, int k, int d, int m, const float *far_val, const int32_t *far_lab,
                              const float *far_rows, void *stream);
+/* Sharded relocation: the global top-m of the ranks' local far-point lists (the all-gathered outputs of
+ * mtp_far_points_f32, `total` = world * m entries in rank order): descending distance, ties to the lowest
+ * global row index, entries without a point (gidx < 0) ignored; positions beyond the number of points are
+ * (-1, -1, -1, 0...) -- what one GPU's search over all points returns (the selection of
+ * np.argpartition(distances, -n_empty), sklearn _k_means_common.pyx:186-187, in a defined order).
+ * *peer_failed (device int32) = 1 if any list carries the mark -2 of a rank whose search failed.  One block. */
+int mtp_far_merge_f32(const float *gval, const int64_t *gidx, const int32_t *glab, const float *grows, int total, int m,
+                      int d, float *val, int64_t *idx, int32_t *lab, float *rows, int32_t *peer_failed, void *stream);
+
 
 /* Whole single-GPU Lloyd run == sklearn _kmeans_single_lloyd (cluster/_kmeans.py:624-752) on
  * already-centred data.  Synchronises the stream every `check_every` iterations to read the
@@ -206,8 +218,9 @@ int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int m
  * loop runs without the host between checks; empty clusters: ncclAllGather of the ranks' local far points.
  *   labels_out [n_local] this rank's labels; C_inout: final centres, identical on every rank;
  *   inertia_out: 1 double (device), the global inertia; n_iter_out: HOST int;
- *   phase_ms_out: NULL, or 3 HOST floats = average milliseconds of (E-step, local sums, all-reduce + M-step finish)
- *     per iteration, from HIP events the library records on `stream`;
+ *   phase_ms_out: NULL, or 4 HOST floats = average milliseconds of (E-step, local sums, all-reduce, M-step finish)
+ *     per iteration, from HIP events the library records on `stream` (created before the first iteration; the
+ *     first 1024 iterations are timed);
  *   options: 0, or MTP_LLOYD_NO_FINAL_ESTEP: when the loop ends on max_iter / the tolerance the closing E-step
  *     (sklearn _kmeans.py:736-748) is left out and labels_out are those of the last iteration -- for callers
  *     that time a fixed number of iterations (bench.py) or run the closing step themselves;
@@ -243,7 +256,8 @@ int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_inout, int 
  * ws: mtp_kpp_workspace_bytes(n, d, l) bytes. */
 /* pot_order: how the float32 potentials (sklearn's candidates_pot / current_pot, _kmeans.py:216, :252) are
  * summed.  MTP_POT_OPENBLAS: in the float addition order of the reference stack -- NumPy handing
- * [L, n] @ [n, 1] to OpenBLAS sgemv_t and [1, n] @ [n] to sdot (0.3.29, x86-64 SkylakeX / Haswell kernels) --
+ * [L, n] @ [n, 1] to OpenBLAS sgemv_t and [1, n] @ [n] to sdot (0.3.29 x86-64: the sgemv_t order is shared by the SkylakeX and Haswell
+ * kernels, the sdot order is the SkylakeX / AVX-512 micro-kernel's only; parity on an AVX2-only host is unpinned) --
  * so that the draws rand = u * pot, and with them the seeds, are sklearn's bit for bit;
  * MTP_POT_F64: double sums rounded to float (a draw within ~1e-7 relative of a cumulative-sum boundary can
  * then pick the neighbouring point). */

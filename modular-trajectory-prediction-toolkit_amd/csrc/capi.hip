@@ -221,10 +221,21 @@ constexpr int kNcclSum = 0, kNcclChar = 0, kNcclDouble = 8;  // rccl.h: ncclSum,
 const Rccl &rccl() {
     static Rccl r = [] {
         Rccl q;
-        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
-        if (h == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-        if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (h == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        void *h = nullptr;
+        // MTP_RCCL_LIB=<path>: bind the six entry points from that library instead (read once, at the first
+        // use).  For collective libraries that are not called librccl.so, and for tests/stub_nccl -- a
+        // shared-memory stand-in that lets several processes on ONE GPU run the sharded loop, which RCCL
+        // refuses.  No fallback when the path does not load: the caller asked for that library.
+        const char *override_path = getenv("MTP_RCCL_LIB");
+        if (override_path != nullptr && override_path[0] != '\0') {
+            h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+            if (h == nullptr) fprintf(stderr, "libmtp_accel: MTP_RCCL_LIB=%s: %s\n", override_path, dlerror());
+        } else {
+            h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+            if (h == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+            if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        }
         if (h == nullptr) return q;
         q.GetUniqueId = reinterpret_cast<decltype(q.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
         q.CommInitRank = reinterpret_cast<decltype(q.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
@@ -304,7 +315,16 @@ extern "C" int mtp_comm_destroy(mtp_comm *c) {
 // would return.  One block; rank by counting (the lists are short, and empty clusters are rare).
 __global__ __launch_bounds__(1024) void k_far_merge(const float *gval, const int64_t *gidx, const int32_t *glab,
                                                     const float *grows, int total, int m, int d, float *val,
-                                                    int64_t *idx, int32_t *lab, float *rows) {
+                                                    int64_t *idx, int32_t *lab, float *rows, int32_t *peer_failed) {
+    // a rank whose far-point search failed still joins the all-gathers, with the value kFarFailed in its list:
+    // every rank sees it in the same gathered data and leaves the loop with an error instead of hanging
+    __shared__ int s_failed;
+    if (threadIdx.x == 0) s_failed = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += blockDim.x)
+        if (gval[e] == -2.f) s_failed = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) *peer_failed = s_failed;
     for (int q = threadIdx.x; q < m; q += blockDim.x) {  // "no candidate" unless a ranked entry lands here
         val[q] = -1.f;
         idx[q] = -1;
@@ -330,15 +350,26 @@ __global__ __launch_bounds__(1024) void k_far_merge(const float *gval, const int
     }
 }
 
-__global__ void k_fill_no_far_points(float *val, int64_t *idx, int32_t *lab, float *rows, int m, int d) {
+__global__ void k_fill_no_far_points(float *val, int64_t *idx, int32_t *lab, float *rows, int m, int d, float mark) {
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < m * d; q += gridDim.x * blockDim.x) {
         rows[q] = 0.f;
         if (q < m) {
-            val[q] = -1.f;
+            val[q] = mark;  // -1: this rank holds no points; -2: its search failed (k_far_merge)
             idx[q] = -1;
             lab[q] = -1;
         }
     }
+}
+
+extern "C" int mtp_far_merge_f32(const float *gval, const int64_t *gidx, const int32_t *glab, const float *grows, int total,
+                                 int m, int d, float *val, int64_t *idx, int32_t *lab, float *rows, int32_t *peer_failed,
+                                 void *stream) {
+    MTP_REQUIRE(gval && gidx && glab && grows && val && idx && lab && rows && peer_failed, "mtp_far_merge: null pointer");
+    MTP_REQUIRE(total >= 0 && m >= 1 && d >= 1, "mtp_far_merge: bad shape total=%d m=%d d=%d", total, m, d);
+    hipLaunchKernelGGL(k_far_merge, dim3(1), dim3(1024), 0, mtp_stream(stream), gval, gidx, glab, grows, total, m, d, val, idx,
+                       lab, rows, peer_failed);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
 }
 
 // ---- whole single-GPU run: sklearn _kmeans_single_lloyd (cluster/_kmeans.py:624-752) ----
@@ -405,22 +436,31 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
     if (rc != MTP_OK) return rc;
     if (n > 0) MTP_HIP(hipMemsetAsync(labels_out, 0xff, (size_t)n * 4, s));  // labels_old = -1 (_kmeans.py:685)
 
-    // optional per-phase timing (bench.py): events around the E-step / the sums / all-reduce + M-step finish
+    // optional per-phase timing (bench.py): events around the E-step / the sums / the all-reduce / the M-step finish.
+    // The events are created here, before anything is timed (5 per iteration, for the first kMaxTimedIters iterations).
+    constexpr int kMarks = 5, kMaxTimedIters = 1024;
     std::vector<hipEvent_t> ev;
-    auto mark = [&]() -> int {
-        if (phase_ms_out == nullptr) return MTP_OK;
-        hipEvent_t e;
-        MTP_HIP(hipEventCreate(&e));
-        ev.push_back(e);
-        MTP_HIP(hipEventRecord(e, s));
-        return MTP_OK;
-    };
     struct EvGuard {
         std::vector<hipEvent_t> &v;
         ~EvGuard() {
             for (hipEvent_t e : v) (void)hipEventDestroy(e);
         }
     } ev_guard{ev};
+    size_t ev_used = 0;
+    if (phase_ms_out != nullptr) {
+        const int timed = max_iter < kMaxTimedIters ? max_iter : kMaxTimedIters;
+        ev.reserve((size_t)timed * kMarks);
+        for (int i = 0; i < timed * kMarks; ++i) {
+            hipEvent_t e;
+            MTP_HIP(hipEventCreate(&e));
+            ev.push_back(e);
+        }
+    }
+    auto mark = [&]() -> int {
+        if (ev_used >= ev.size()) return MTP_OK;
+        MTP_HIP(hipEventRecord(ev[ev_used++], s));
+        return MTP_OK;
+    };
 
     // one iteration: E-step, local sums, [all-reduce], M-step finish (pauses on an empty cluster)
     auto iteration = [&](const float *c_old, float *c_new) -> int {
@@ -439,6 +479,8 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
         r = mark();
         if (r != MTP_OK) return r;
         if (cm != nullptr) MTP_NCCL(rccl().AllReduce(w.red, w.red, (size_t)red_len, kNcclDouble, kNcclSum, cm->nccl, s));
+        r = mark();
+        if (r != MTP_OK) return r;
         r = mtp_launch_mstep(w.red, c_old, c_new, k, d, tol_abs, max_iter, 0, w.staged, w.c2, w.shift, w.flags,
                              cm != nullptr ? sw.red_backup : nullptr, s);
         if (r != MTP_OK) return r;
@@ -466,13 +508,17 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
             // red are valid.  The centres it read are in parity (done_iters & 1).
             const int old = done_iters & 1;
             const int m = hflags[MTP_FLAG_N_EMPTY];  // < k: at least one cluster holds points
+            int far_rc = MTP_OK;
             if (n > 0) {
-                rc = mtp_far_points_f32(X, n, d, cbuf[old], labels_out, m, row_offset, w.far_val, w.far_idx, w.far_lab,
-                                        w.far_rows, dist_scratch, stream);
-                if (rc != MTP_OK) return rc;
-            } else {
+                far_rc = mtp_far_points_f32(X, n, d, cbuf[old], labels_out, m, row_offset, w.far_val, w.far_idx, w.far_lab,
+                                            w.far_rows, dist_scratch, stream);
+                if (far_rc != MTP_OK && cm == nullptr) return far_rc;
+            }
+            if (n == 0 || far_rc != MTP_OK) {
+                // no points here -- or the search failed: the other ranks are about to enter the all-gathers, so
+                // this rank joins them with a marked list and everyone returns an error together (k_far_merge)
                 hipLaunchKernelGGL(k_fill_no_far_points, dim3(64), dim3(256), 0, s, w.far_val, w.far_idx, w.far_lab, w.far_rows,
-                                   m, d);
+                                   m, d, far_rc != MTP_OK ? -2.f : -1.f);
                 MTP_LAUNCH_CHECK();
             }
             if (cm != nullptr) {
@@ -482,8 +528,17 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
                 MTP_NCCL(rccl().AllGather(w.far_lab, sw.g_lab, (size_t)m * 4, kNcclChar, cm->nccl, s));
                 MTP_NCCL(rccl().AllGather(w.far_rows, sw.g_rows, (size_t)m * d * 4, kNcclChar, cm->nccl, s));
                 hipLaunchKernelGGL(k_far_merge, dim3(1), dim3(1024), 0, s, sw.g_val, sw.g_idx, sw.g_lab, sw.g_rows,
-                                   cm->world * m, m, d, w.far_val, w.far_idx, w.far_lab, w.far_rows);
+                                   cm->world * m, m, d, w.far_val, w.far_idx, w.far_lab, w.far_rows,
+                                   w.flags + MTP_FLAG_PEER_FAILED);
                 MTP_LAUNCH_CHECK();
+                int32_t peer_failed = 0;  // relocations are rare and already a host sync point: one more word
+                MTP_HIP(hipMemcpyAsync(&peer_failed, w.flags + MTP_FLAG_PEER_FAILED, 4, hipMemcpyDeviceToHost, s));
+                MTP_HIP(hipStreamSynchronize(s));
+                if (far_rc != MTP_OK) return far_rc;  // this rank's own error (mtp_last_error() still names it)
+                if (peer_failed != 0) {
+                    mtp_set_error("mtp_lloyd_sharded: the far-point search failed on another rank; all ranks stop");
+                    return MTP_E_COMM;
+                }
             }
             rc = mtp_apply_relocation_f32(w.red, k, d, m, w.far_val, w.far_lab, w.far_rows, stream);
             if (rc != MTP_OK) return rc;
@@ -521,16 +576,16 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
     MTP_HIP(hipStreamSynchronize(s));
     if (phase_ms_out != nullptr) {
         // averages over the iterations that ran (an attempt enqueued behind a pause or the end is a no-op)
-        double acc[3] = {0, 0, 0};
+        double acc[kMarks - 1] = {0, 0, 0, 0};
         int cnt = 0;
-        for (size_t e = 0; e + 3 < ev.size() && cnt < n_iter; e += 4, ++cnt) {
-            for (int ph = 0; ph < 3; ++ph) {
+        for (size_t e = 0; e + kMarks <= ev_used && cnt < n_iter; e += kMarks, ++cnt) {
+            for (int ph = 0; ph < kMarks - 1; ++ph) {
                 float ms = 0.f;
                 MTP_HIP(hipEventElapsedTime(&ms, ev[e + ph], ev[e + ph + 1]));
                 acc[ph] += ms;
             }
         }
-        for (int ph = 0; ph < 3; ++ph) phase_ms_out[ph] = cnt ? (float)(acc[ph] / cnt) : 0.f;
+        for (int ph = 0; ph < kMarks - 1; ++ph) phase_ms_out[ph] = cnt ? (float)(acc[ph] / cnt) : 0.f;
     }
     return MTP_OK;
 }

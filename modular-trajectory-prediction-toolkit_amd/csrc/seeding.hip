@@ -661,8 +661,9 @@ static int launch_kpp_dist(const float *X, int64_t n, int d, int n_cand, const K
 // products are exact and only the order of the float additions shows.  The draws are rand = u * pot,
 // so a potential that differs in its last bit moves a draw across a cumulative-sum boundary about once
 // in a few thousand draws at N ~ 7e4 -- enough to change the seeds of one restart in four (measured).
-// The orders below are those of OpenBLAS 0.3.29's x86-64 kernels (SkylakeX / Haswell; independent of the
-// thread count), established against NumPy itself and restated in oracle/oracle.c:
+// The orders below are those of OpenBLAS 0.3.29's x86-64 kernels (sgemv_t: shared by the SkylakeX and Haswell
+// kernels; sdot: the SkylakeX / AVX-512 micro-kernel only -- Haswell's sdot runs 4 x 8 lanes over n & -32, another
+// order, so on an AVX2-only host the first-centre potential is unpinned; independent of the thread count), established against NumPy itself and restated in oracle/oracle.c:
 //   sgemv_t: blocks of 4096 points (the last (n & 4095) - (n & 3)), y += block sum, block by block, then the
 //            n & 3 trailing points as y += ((a0 + a1) + a2).  Rows in groups: fours and a last single row
 //            by an 8-lane kernel (lane l adds points l, l+8, ...; a block whose length has bit 2 set gives

@@ -729,16 +729,21 @@ __global__ __launch_bounds__(256) void k_apply_relocation(double *red, int k, in
                                                           const float *__restrict__ far_val,
                                                           const int32_t *__restrict__ far_lab,
                                                           const float *__restrict__ far_rows) {
-    // single block; sequential over the empty clusters like the reference loop (:197-211)
+    // single block; sequential over the empty clusters like the reference loop (:197-211).
+    // sklearn fixes `empty_clusters = where(weight_in_clusters == 0)` BEFORE the loop (:176): a cluster that
+    // loses its only member to a relocation during the loop is not served.  The snapshot is kept in the
+    // counts themselves: the originally empty clusters are marked -0.0 (a count that drops 1 -> 0 is +0.0).
     if (!(far_val[0] > 0.f)) return;  // np.max(distances) == 0: relocating is pointless
     double *counts = red + (size_t)k * d;
+    for (int j = threadIdx.x; j < k; j += blockDim.x)
+        if (counts[j] == 0.0) counts[j] = -0.0;
     __shared__ int s_new;   // the empty cluster served in this round (ascending id), k = none left
     if (threadIdx.x == 0) s_new = -1;
     __syncthreads();
     for (int i = 0; i < m; ++i) {
         if (threadIdx.x == 0) {
             int j = s_new + 1;
-            while (j < k && counts[j] != 0.0) ++j;
+            while (j < k && !(counts[j] == 0.0 && signbit(counts[j]))) ++j;
             s_new = j;
         }
         __syncthreads();
@@ -756,6 +761,8 @@ __global__ __launch_bounds__(256) void k_apply_relocation(double *red, int k, in
         }
         __syncthreads();
     }
+    for (int j = threadIdx.x; j < k; j += blockDim.x)  // unserved marks (fewer far points than empty clusters)
+        if (counts[j] == 0.0) counts[j] = 0.0;
 }
 
 extern "C" int mtp_apply_relocation_f32(double *red, int k, int d, int m, const float *far_val, const int32_t *far_lab,

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mtp_far_points_scratch_bytes": (_i64, [_i64]),
     "mtp_far_points_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mtp_apply_relocation_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mtp_far_merge_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mtp_lloyd_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _f64, _i32, _vp, _vp, ctypes.POINTER(ctypes.c_int), _vp,
                              _sz, _vp]),
     "mtp_comm_unique_id": (_i32, [_vp]),

@@ -386,7 +386,7 @@ def lloyd_sharded_native(comm, X_local, C0, row_offset, n_total, max_iter=300, t
     """sklearn ``_kmeans_single_lloyd`` over row-sharded centred points, the whole loop inside the library
     (``mtp_lloyd_sharded_f32``: RCCL all-reduce of the packed sums between the library's own kernels).
     ``comm`` None: one rank holding all points.
-    Returns (labels_local int32, inertia (global), centers [K, D], n_iter[, phase_ms (3 floats)])."""
+    Returns (labels_local int32, inertia (global), centers [K, D], n_iter[, phase_ms (4 floats: E-step, sums, all-reduce, M-step finish)])."""
     import ctypes
     n, d = X_local.shape
     k = C0.shape[0]
@@ -397,7 +397,7 @@ def lloyd_sharded_native(comm, X_local, C0, row_offset, n_total, max_iter=300, t
     ws_bytes = int(lib().mtp_lloyd_sharded_workspace_bytes(k, d, n, comm.world if comm is not None else 1))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     n_iter = ctypes.c_int(0)
-    phase = (ctypes.c_float * 3)() if want_phase_ms else None
+    phase = (ctypes.c_float * 4)() if want_phase_ms else None
     with torch.cuda.device(dev):
         check(lib().mtp_lloyd_sharded_f32(comm.handle if comm is not None else None, ptr(X_local) if n else None, n, int(row_offset), int(n_total), d, ptr(C),
                                           k, int(max_iter), float(tol_abs), int(check_every), ptr(labels) if n else None,

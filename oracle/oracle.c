@@ -276,7 +276,8 @@ ORC_BEST_OF_K(orc_best_of_k_f32, orc_ade_fde_f32, float)
 ORC_BEST_OF_K(orc_best_of_k_f64, orc_ade_fde_f64, double)
 
 /* ------------------------------------------------------------------------------------
- * Float32 row sums in the order NumPy 2.2 + OpenBLAS 0.3.29 (x86-64 "SkylakeX"/Haswell kernels, the
+ * Float32 row sums in the order NumPy 2.2 + OpenBLAS 0.3.29 (x86-64; sgemv_t as in the "SkylakeX" and Haswell
+ * kernels, sdot as in the SkylakeX / AVX-512 micro-kernel only -- AVX2-only hosts are unpinned; the
  * build container's stack, where the golden fixtures were generated) produce for the two products
  * sklearn's k-means++ forms with a unit weight vector (sklearn cluster/_kmeans.py:216 and :252):
  *   candidates_pot = distance_to_candidates @ sample_weight.reshape(-1, 1)   [L, n] @ [n, 1] -> sgemv_t

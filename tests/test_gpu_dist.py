@@ -160,7 +160,7 @@ def test_in_library_rccl_loop(which, tmp_path, gpu_device):
     assert np.array_equal(p["centers"], single["centers"].cpu().numpy())
     assert float(p["inertia"]) == single["inertia"]
     assert int(p["it5"]) == min(5, single["n_iter"]) or which != "plain"
-    assert p["phase"].shape == (3,) and (p["phase"] >= 0).all() and p["phase"][0] > 0
+    assert p["phase"].shape == (4,) and (p["phase"] >= 0).all() and p["phase"][0] > 0
 
 
 def _pp_case(n=6007):

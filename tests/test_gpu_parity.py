@@ -297,6 +297,34 @@ def test_relocation_of_more_than_64_empty_clusters(gpu_device):
         assert nb[r] == n1 and torch.equal(lb[r], l1) and torch.equal(cb[r], c1)
 
 
+
+def test_relocation_serves_only_the_originally_empty_clusters(gpu_device):
+    """sklearn fixes `empty_clusters = where(weight_in_clusters == 0)` before its loop
+    (_k_means_common.pyx:176): when a far point is the only member of its cluster, that cluster drops to
+    zero during the loop but is NOT served; the last originally empty cluster is."""
+    from pccs_accel._lib import check, lib, ptr, stream_ptr
+    k, d, m = 4, 2, 2
+    sums = np.array([[0, 0], [7, 8], [0, 0], [10, 20]], dtype=np.float64)
+    counts = np.array([0, 1, 0, 5], dtype=np.float64)          # clusters 0 and 2 are empty, cluster 1 is a singleton
+    red = dev(np.concatenate([sums.ravel(), counts, [0, 0]]), gpu_device)
+    far_val = dev(np.array([9.0, 4.0], dtype=np.float32), gpu_device)
+    far_lab = dev(np.array([1, 3], dtype=np.int32), gpu_device)   # the farthest point IS cluster 1's only member
+    far_rows = dev(np.array([[7, 8], [1, 2]], dtype=np.float32), gpu_device)
+    check(lib().mtp_apply_relocation_f32(ptr(red), k, d, m, ptr(far_val), ptr(far_lab), ptr(far_rows), stream_ptr()),
+          "mtp_apply_relocation_f32")
+    out = red.cpu().numpy()
+    assert out[k * d:k * d + k].tolist() == [1, 0, 1, 4]
+    assert not np.signbit(out[k * d:k * d + k]).any()
+    assert out[:k * d].reshape(k, d).tolist() == [[7, 8], [0, 0], [1, 2], [9, 18]]
+    # fewer far points than empty clusters: the unserved mark is cleared again
+    red = dev(np.concatenate([sums.ravel(), counts, [0, 0]]), gpu_device)
+    far_lab = dev(np.array([3, -1], dtype=np.int32), gpu_device)
+    check(lib().mtp_apply_relocation_f32(ptr(red), k, d, m, ptr(far_val), ptr(far_lab), ptr(far_rows), stream_ptr()),
+          "mtp_apply_relocation_f32")
+    out = red.cpu().numpy()
+    assert out[k * d:k * d + k].tolist() == [1, 1, 0, 4] and not np.signbit(out[k * d:k * d + k]).any()
+
+
 # ------------------------------------------------------------------------------------------
 # ADE / FDE and best-of-K
 # ------------------------------------------------------------------------------------------

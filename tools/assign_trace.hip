@@ -5,7 +5,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "assign_kernel.h"
+#include "assign_variants.h"
 
 #define CK(x)                                                                      \
     do {                                                                           \

@@ -6,7 +6,7 @@
 #include <cstring>
 #include <vector>
 
-#include "assign_kernel.h"
+#include "assign_variants.h"
 
 #define CK(x)                                                                      \
     do {                                                                           \
