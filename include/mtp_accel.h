@@ -166,7 +166,8 @@ int mtp_lloyd_accumulate_f32(const float *X, int64_t n, int d, const int32_t *la
  * mtp_apply_relocation_f32 and calls this again with relocation_done = 1.
  * red_backup (NULL or mtp_red_len doubles): on that pause red is MOVED there (red is zeroed),
  * so that all-reduces a multi-GPU driver has already enqueued behind the pause add zeros
- * instead of re-summing the reduced buffer; the driver copies it back before relocating. */
+ * instead of re-summing the reduced buffer; the driver copies it back before relocating.
+ * tol < 0 (never sklearn's): no convergence test of either kind, the loop runs max_iter iterations. */
 int mtp_lloyd_mstep_f32(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
                         int relocation_done, float *staged, float *c2, float *shift, int32_t *flags,
                         double *red_backup, void *stream);

@@ -244,7 +244,9 @@ __global__ __launch_bounds__(1024) void k_mstep_flags(double *red, int k, int d,
         flags[MTP_FLAG_N_ITER] = it;
         flags[MTP_FLAG_N_EMPTY] = 0;
         int st = MTP_STATE_RUNNING;
-        if (n_changed == 0.0)
+        // tol < 0 (sklearn's is never negative): a fixed number of iterations, no convergence test of either
+        // kind -- for callers that time exactly max_iter iterations (bench.py)
+        if (n_changed == 0.0 && tol >= 0.0)
             st = MTP_STATE_STRICT;
         else if (tot <= tol)
             st = MTP_STATE_TOL;

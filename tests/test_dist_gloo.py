@@ -79,7 +79,7 @@ class NumpyOps:
         it = int(flags[1]) + 1
         flags[1] = it
         flags[2] = 0
-        flags[0] = 1 if n_changed == 0 else (2 if tot <= tol else (4 if it >= max_iter else 0))
+        flags[0] = 1 if (n_changed == 0 and tol >= 0) else (2 if tot <= tol else (4 if it >= max_iter else 0))
 
     def far_points(self, X, C_old, labels, m, idx_offset):
         n, d = X.shape
