@@ -172,6 +172,11 @@ int mtp_lloyd_mstep_f32(double *red, const float *C_old, float *C_new, int k, in
                         int relocation_done, float *staged, float *c2, float *shift, int32_t *flags,
                         double *red_backup, void *stream);
 
+/* (v ** 2).sum() of a contiguous float32 array in NumPy's pairwise summation order (sklearn _kmeans.py:722,
+ * center_shift_tot = (center_shift**2).sum(); numpy/_core/src/umath/loops_utils.h.src) -- the total shift of
+ * MTP_LLOYD_SUMS_SKLEARN_1T, exposed for its parity test.  out: 1 float (device).  One thread. */
+int mtp_pairwise_sumsq_f32(const float *v, int n, float *out, void *stream);
+
 /* Empty-cluster relocation, sklearn cluster/_k_means_common.pyx:167-211.
  * mtp_far_points_f32: the m points farthest from their assigned (old) centre, by
  * descending ||x - c||^2 (float, direct form), ties to the lowest index:
@@ -203,9 +208,22 @@ int mtp_far_merge_f32(const float *gval, const int64_t *gidx, const int32_t *gla
  * flags; kernels of iterations enqueued past convergence are no-ops.
  *   C_inout [k, d] initial centres in, final centres out;  labels_out [n]
  *   inertia_out: 1 double (device);  n_iter_out: 1 int (HOST pointer)
+ *   options: 0 or a sum of MTP_LLOYD_* values:
+ *     MTP_LLOYD_NO_FINAL_ESTEP (see mtp_lloyd_sharded_f32);
+ *     MTP_LLOYD_SUMS_SKLEARN_1T: the bit-exact comparison mode.  By default the centroid sums are doubles, so the
+ *       run does not depend on the workgroup schedule or the GPU count; sklearn's are float32 sums whose order
+ *       depends on its thread scheduling (_k_means_lloyd.pyx:143-152), so no two multi-threaded sklearn runs
+ *       agree bit for bit.  With ONE thread sklearn is deterministic: every (cluster, feature) sum is a float32
+ *       chain over the member rows in row order (:215-218), the counts are floats, the total shift is NumPy's
+ *       pairwise float32 sum of center_shift**2 (_kmeans.py:722), the inertia a float32 chain over the points
+ *       (_k_means_common.pyx:116-124).  This option forms exactly those, so that a whole
+ *       np.random.seed(s); KMeans(K, n_init=20).fit(X) under threadpool_limits(1) is reproduced bit for bit
+ *       (fixture G15).  Slower (one wave per cluster walks the labels); one GPU only.
  *   ws: mtp_lloyd_workspace_bytes(k, d) + mtp_far_points_scratch_bytes(n) bytes of device scratch */
+#define MTP_LLOYD_NO_FINAL_ESTEP 1
+#define MTP_LLOYD_SUMS_SKLEARN_1T 2
 int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int max_iter, double tol_abs,
-                  int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, void *ws,
+                  int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, int options, void *ws,
                   size_t ws_bytes, void *stream);
 
 /* ---- the same run with the points sharded over the GPUs of a node: one process per GPU, RCCL over xGMI ----
@@ -225,10 +243,10 @@ int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int m
  *   options: 0, or MTP_LLOYD_NO_FINAL_ESTEP: when the loop ends on max_iter / the tolerance the closing E-step
  *     (sklearn _kmeans.py:736-748) is left out and labels_out are those of the last iteration -- for callers
  *     that time a fixed number of iterations (bench.py) or run the closing step themselves;
+ *     MTP_LLOYD_SUMS_SKLEARN_1T is accepted only when one rank holds all points;
  *   ws: mtp_lloyd_sharded_workspace_bytes(k, d, n_local, world) bytes.
  * Every rank must call with the same k, d, max_iter, tol_abs, check_every.  comm == NULL: one rank holding all
  * points (mtp_lloyd_f32 with the timing / options arguments). */
-#define MTP_LLOYD_NO_FINAL_ESTEP 1
 typedef struct mtp_comm mtp_comm;
 int mtp_comm_unique_id(void *id_out);
 int mtp_comm_create(int rank, int world, const void *id, mtp_comm **out);
@@ -243,11 +261,12 @@ int mtp_lloyd_sharded_f32(const mtp_comm *comm, const float *X_local, int64_t n_
  * PCCSNet/utils/utility.py:120-121 runs with n_init=20): `batch` independent mtp_lloyd_f32 runs on the same
  * points sharing every launch, each with its own state / convergence.  d must be 64, 96 or 128.
  *   C_inout [batch, k, d]; labels_out [batch, n]; inertia_out [batch] doubles (device);
- *   n_iter_out [batch] ints (HOST);  ws: mtp_lloyd_batched_workspace_bytes(k, d, batch, n) bytes. */
+ *   n_iter_out [batch] ints (HOST);  options: 0 or MTP_LLOYD_SUMS_SKLEARN_1T (mtp_lloyd_f32);
+ *   ws: mtp_lloyd_batched_workspace_bytes(k, d, batch, n) bytes. */
 int64_t mtp_lloyd_batched_workspace_bytes(int k, int d, int batch, int64_t n);
 int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_inout, int k, int batch, int max_iter,
                           double tol_abs, int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out,
-                          void *ws, size_t ws_bytes, void *stream);
+                          int options, void *ws, size_t ws_bytes, void *stream);
 
 /* k-means++ seeding, sklearn cluster/_kmeans.py:174-272 with unit sample weights, for one
  * restart.  The caller draws the random numbers from the same NumPy RandomState in sklearn's

@@ -431,6 +431,13 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
     hipStream_t s = mtp_stream(stream);
     if (check_every < 1) check_every = 1;
     const int64_t red_len = mtp_red_len(k, d);
+    // MTP_LLOYD_SUMS_SKLEARN_1T: centroid sums, the total shift and the inertia in the float32 orders of a one-thread
+    // sklearn run (row-order chains): one rank only -- a chain does not split over ranks without taking turns
+    const int sums_mode = options & MTP_LLOYD_SUMS_SKLEARN_1T;
+    MTP_REQUIRE(sums_mode == 0 || cm == nullptr || cm->world == 1,
+                "mtp_lloyd_sharded: MTP_LLOYD_SUMS_SKLEARN_1T needs all points on one rank (world = %d)", cm ? cm->world : 1);
+    MTP_REQUIRE(sums_mode == 0 || k <= 8192, "mtp_lloyd: MTP_LLOYD_SUMS_SKLEARN_1T supports k <= 8192 (NumPy's pairwise "
+                "order of the total shift is only restated up to its buffer size), got k = %d", k);
 
     int rc = mtp_lloyd_begin_f32(C_inout, k, d, w.staged, w.c2, w.red, w.flags, stream);
     if (rc != MTP_OK) return rc;
@@ -473,7 +480,8 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
         r = mark();
         if (r != MTP_OK) return r;
         if (n > 0) {
-            r = mtp_lloyd_accumulate_f32(X, n, d, labels_out, k, w.red, w.flags, stream);
+            r = mtp_launch_accumulate(X, n, d, labels_out, k, w.red, w.red + (size_t)k * d, w.flags + MTP_FLAG_STATE, s,
+                                      mtp_no_batch(), sums_mode);
             if (r != MTP_OK) return r;
         }
         r = mark();
@@ -482,7 +490,7 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
         r = mark();
         if (r != MTP_OK) return r;
         r = mtp_launch_mstep(w.red, c_old, c_new, k, d, tol_abs, max_iter, 0, w.staged, w.c2, w.shift, w.flags,
-                             cm != nullptr ? sw.red_backup : nullptr, s);
+                             cm != nullptr ? sw.red_backup : nullptr, s, mtp_no_batch(), 0, sums_mode);
         if (r != MTP_OK) return r;
         return mark();
     };
@@ -540,11 +548,11 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
                     return MTP_E_COMM;
                 }
             }
-            rc = mtp_apply_relocation_f32(w.red, k, d, m, w.far_val, w.far_lab, w.far_rows, stream);
+            rc = mtp_launch_apply_relocation(w.red, k, d, m, w.far_val, w.far_lab, w.far_rows, sums_mode, s);
             if (rc != MTP_OK) return rc;
             MTP_HIP(hipMemsetAsync(w.flags + MTP_FLAG_STATE, 0, 4, s));
             rc = mtp_launch_mstep(w.red, cbuf[old], cbuf[old ^ 1], k, d, tol_abs, max_iter, 1, w.staged, w.c2, w.shift,
-                                  w.flags, nullptr, s);
+                                  w.flags, nullptr, s, mtp_no_batch(), 0, sums_mode);
             if (rc != MTP_OK) return rc;
             cur = old ^ 1;
             enq_iters = done_iters + 1;
@@ -566,7 +574,10 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
     if (fin != 0) MTP_HIP(hipMemcpyAsync(C_inout, w.c_alt, (size_t)k * d * 4, hipMemcpyDeviceToDevice, s));
     if (inertia_out != nullptr) {
         MTP_HIP(hipMemsetAsync(inertia_out, 0, 8, s));
-        if (n > 0) {
+        if (sums_mode != 0) {  // sklearn's float32 chain; the far-point scratch (n floats) holds the per-point distances
+            rc = mtp_launch_inertia_chain_f32(X, n, d, cbuf[fin], labels_out, inertia_out, dist_scratch, 1, 0, 0, s);
+            if (rc != MTP_OK) return rc;
+        } else if (n > 0) {
             rc = mtp_launch_inertia(X, n, d, cbuf[fin], labels_out, inertia_out, nullptr, s);
             if (rc != MTP_OK) return rc;
         }
@@ -591,13 +602,13 @@ static int lloyd_run(const mtp_comm *cm, const float *X, int64_t n, int64_t row_
 }
 
 extern "C" int mtp_lloyd_f32(const float *X, int64_t n, int d, float *C_inout, int k, int max_iter, double tol_abs,
-                             int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, void *ws,
-                             size_t ws_bytes, void *stream) {
+                             int check_every, int32_t *labels_out, double *inertia_out, int *n_iter_out, int options,
+                             void *ws, size_t ws_bytes, void *stream) {
     MTP_REQUIRE(X && C_inout && labels_out && ws, "mtp_lloyd: null pointer");
     MTP_REQUIRE(n >= k && k >= 1 && d >= 1 && max_iter >= 1, "mtp_lloyd: bad shape n=%lld k=%d d=%d max_iter=%d",
                 (long long)n, k, d, max_iter);
     return lloyd_run(nullptr, X, n, 0, d, C_inout, k, max_iter, tol_abs, check_every, labels_out, inertia_out, n_iter_out,
-                     nullptr, 0, ws, ws_bytes, stream);
+                     nullptr, options, ws, ws_bytes, stream);
 }
 
 extern "C" int mtp_lloyd_sharded_f32(const mtp_comm *comm, const float *X_local, int64_t n_local, int64_t row_offset,
@@ -628,8 +639,10 @@ extern "C" int mtp_lloyd_sharded_f32(const mtp_comm *comm, const float *X_local,
 // iteration is launch-bound; 20 restarts per launch are what makes the fit fast.
 extern "C" int64_t mtp_lloyd_batched_workspace_bytes(int k, int d, int batch, int64_t n) {
     if (k <= 0 || d <= 0 || batch <= 0 || n < 0) return 0;
+    // per restart the Lloyd buffers; the far-point scratch; the packed flags; batch * n floats of per-point distances
+    // (the float32 inertia chains of MTP_LLOYD_SUMS_SKLEARN_1T)
     return (int64_t)(carve_lloyd(nullptr, k, d).bytes * (size_t)batch + (size_t)mtp_far_points_scratch_bytes(n) +
-                     align_up((size_t)batch * MTP_FLAG_WORDS * 4, 256));
+                     align_up((size_t)batch * MTP_FLAG_WORDS * 4, 256) + align_up((size_t)batch * (size_t)n * 4, 256));
 }
 
 // the restarts' flag words, gathered into one contiguous block for a single plain copy to the host
@@ -640,7 +653,7 @@ __global__ void k_collect_flags(const int32_t *flags, size_t stride_words, int b
 
 extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_inout, int k, int batch, int max_iter,
                                      double tol_abs, int check_every, int32_t *labels_out, double *inertia_out,
-                                     int *n_iter_out, void *ws, size_t ws_bytes, void *stream) {
+                                     int *n_iter_out, int options, void *ws, size_t ws_bytes, void *stream) {
     MTP_REQUIRE(X && C_inout && labels_out && ws, "mtp_lloyd_batched: null pointer");
     MTP_REQUIRE(n >= k && k >= 1 && d >= 1 && max_iter >= 1, "mtp_lloyd_batched: bad shape n=%lld k=%d d=%d max_iter=%d",
                 (long long)n, k, d, max_iter);
@@ -654,6 +667,9 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
     }
     float *dist_scratch = reinterpret_cast<float *>(static_cast<char *>(ws) + w.bytes * (size_t)batch);
     int32_t *flags_packed = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(dist_scratch) + (size_t)mtp_far_points_scratch_bytes(n));
+    float *per_point = reinterpret_cast<float *>(reinterpret_cast<char *>(flags_packed) + align_up((size_t)batch * MTP_FLAG_WORDS * 4, 256));
+    const int sums_mode = options & MTP_LLOYD_SUMS_SKLEARN_1T;
+    MTP_REQUIRE(sums_mode == 0 || k <= 8192, "mtp_lloyd_batched: MTP_LLOYD_SUMS_SKLEARN_1T supports k <= 8192, got k = %d", k);
     hipStream_t s = mtp_stream(stream);
     if (check_every < 1) check_every = 1;
     MtpBatchStride bs;
@@ -692,10 +708,10 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
             // centres of a restart: buffer (n_iter & 1); the MFMA E-step only reads the staged image
             rc = mtp_launch_assign(X, n, d, nullptr, w.staged, w.c2, k, labels_out, w.red + (size_t)k * d + k, w.flags, s, bs);
             if (rc != MTP_OK) return rc;
-            rc = mtp_launch_accumulate(X, n, d, labels_out, k, w.red, w.red + (size_t)k * d, w.flags, s, bs);
+            rc = mtp_launch_accumulate(X, n, d, labels_out, k, w.red, w.red + (size_t)k * d, w.flags, s, bs, sums_mode);
             if (rc != MTP_OK) return rc;
             rc = mtp_launch_mstep(w.red, C_inout, w.c_alt, k, d, tol_abs, max_iter, 0, w.staged, w.c2, w.shift, w.flags,
-                                  nullptr, s, bs, 1);
+                                  nullptr, s, bs, 1, sums_mode);
             if (rc != MTP_OK) return rc;
         }
         rc = read_flags();
@@ -711,14 +727,14 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
                 rc = mtp_far_points_f32(X, n, d, old ? c1 : c0, labels_out + (size_t)b * n, m, 0, at(w.far_val, b),
                                         at(w.far_idx, b), at(w.far_lab, b), at(w.far_rows, b), dist_scratch, stream);
                 if (rc != MTP_OK) return rc;
-                rc = mtp_apply_relocation_f32(at(w.red, b), k, d, m, at(w.far_val, b), at(w.far_lab, b), at(w.far_rows, b),
-                                              stream);
+                rc = mtp_launch_apply_relocation(at(w.red, b), k, d, m, at(w.far_val, b), at(w.far_lab, b), at(w.far_rows, b),
+                                                 sums_mode, s);
                 if (rc != MTP_OK) return rc;
                 MTP_HIP(hipMemsetAsync(at(w.flags, b) + MTP_FLAG_STATE, 0, 4, s));
                 MtpBatchStride one = bs;
                 one.batch = 1;
                 rc = mtp_launch_mstep(at(w.red, b), c0, c1, k, d, tol_abs, max_iter, 1, at(w.staged, b), at(w.c2, b),
-                                      at(w.shift, b), at(w.flags, b), nullptr, s, one, 1);
+                                      at(w.shift, b), at(w.flags, b), nullptr, s, one, 1, sums_mode);
                 if (rc != MTP_OK) return rc;
                 any_live = true;
             } else if (f[MTP_FLAG_STATE] == MTP_STATE_RUNNING) {
@@ -746,7 +762,9 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
         if (n_iter_out != nullptr) n_iter_out[b] = n_iter;
     }
     if (inertia_out != nullptr) {  // all restarts in one launch
-        rc = mtp_launch_inertia_batched(X, n, d, C_inout, labels_out, inertia_out, nullptr, batch, (size_t)k * d, (size_t)n, s);
+        rc = sums_mode != 0
+                 ? mtp_launch_inertia_chain_f32(X, n, d, C_inout, labels_out, inertia_out, per_point, batch, (size_t)k * d, (size_t)n, s)
+                 : mtp_launch_inertia_batched(X, n, d, C_inout, labels_out, inertia_out, nullptr, batch, (size_t)k * d, (size_t)n, s);
         if (rc != MTP_OK) return rc;
     }
     MTP_HIP(hipStreamSynchronize(s));

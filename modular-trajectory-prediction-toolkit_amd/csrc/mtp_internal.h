@@ -112,17 +112,26 @@ int mtp_launch_stage_centers(const float *C, int k, int d, float *staged, float 
 int mtp_launch_assign(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2, int k,
                       int32_t *labels, double *n_changed, const int32_t *state, hipStream_t s,
                       MtpBatchStride bs = mtp_no_batch());
+// sums_mode: 0 = double sums (schedule-independent, the default) or MTP_LLOYD_SUMS_SKLEARN_1T = float32 row-order
+// chains, what sklearn forms with one thread (the bit-exact comparison mode)
 int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,
-                          double *counts, const int32_t *state, hipStream_t s, MtpBatchStride bs = mtp_no_batch());
+                          double *counts, const int32_t *state, hipStream_t s, MtpBatchStride bs = mtp_no_batch(),
+                          int sums_mode = 0);
 // flag_parity = 0: C_old / C_new as given.  1 (batched runs): C_old is buffer 0 of the restart, C_new
 // buffer 1, swapped when the restart's n_iter is odd -- restarts drift apart when one of them pauses.
 int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
                      int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, double *red_backup,
-                     hipStream_t s, MtpBatchStride bs = mtp_no_batch(), int flag_parity = 0);
+                     hipStream_t s, MtpBatchStride bs = mtp_no_batch(), int flag_parity = 0, int sums_mode = 0);
 int mtp_launch_inertia(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
                        float *per_point, hipStream_t s);
 int mtp_launch_inertia_batched(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
                                float *per_point, int batch, size_t c_stride, size_t lab_stride, hipStream_t s);
+
+// sklearn's one-thread float32 inertia (per-point float distances added in row order); per_point_scratch: batch * n floats
+int mtp_launch_inertia_chain_f32(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
+                                 float *per_point_scratch, int batch, size_t c_stride, size_t lab_stride, hipStream_t s);
+int mtp_launch_apply_relocation(double *red, int k, int d, int m, const float *far_val, const int32_t *far_lab,
+                                const float *far_rows, int sums_mode, hipStream_t s);
 
 // ||row||^2 in NumPy einsum("ij,ij->i") float order (see oracle.c orc_row_sqnorm_f32): four lane
 // accumulators, product rounded then added, blocks of 16 consumed vector 3,2,1,0, tail vectors in

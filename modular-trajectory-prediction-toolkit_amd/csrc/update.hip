@@ -27,11 +27,76 @@ __global__ __launch_bounds__(256) void k_accumulate_scalar(const float *__restri
     for (int c = 0; c < d; ++c) atomicAdd(&sums[(size_t)lab * d + c], (double)X[row * d + c]);
 }
 
+// MTP_LLOYD_SUMS_SKLEARN_1T: the sums sklearn forms with ONE thread (cluster/_k_means_lloyd.pyx:215-218; the
+// thread-local buffer every row is added into is itself added once to zeros, :143-152): per (cluster, feature) a
+// float32 chain over the member rows in row order, and float32 counts.  One wave per (cluster, restart, block of
+// 128 features): it scans all labels in order (L2-resident) and adds its members' rows as it meets them, lane l
+// owning features l and l + 64 of the block.  The chain is what bounds it (a dependent v_add_f32 per member row,
+// its row fetched a few rows ahead), not memory: this is the bit-exact comparison mode, not the fast path.
+// The float results are stored into the double reduce buffer (exactly), overwriting it.
+__global__ __launch_bounds__(64) void k_accumulate_chain(const float *__restrict__ X, int64_t n, int d,
+                                                         const int32_t *__restrict__ labels, int k, double *sums,
+                                                         double *counts, const int32_t *state, MtpBatchStride bs) {
+    {
+        const size_t b = blockIdx.y;  // restart
+        labels += b * bs.labels;
+        sums += b * bs.red;
+        counts += b * bs.red;
+        if (state != nullptr) state += b * bs.flags;
+    }
+    if (state != nullptr && *state != MTP_STATE_RUNNING) return;
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const int f0 = blockIdx.z * 128 + lane, f1 = f0 + 64;
+    const bool has0 = f0 < d, has1 = f1 < d;
+    float acc0 = 0.f, acc1 = 0.f, cnt = 0.f;
+    int lab_next = (lane < n) ? labels[lane] : -1;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int lab = lab_next;
+        lab_next = (base + 64 + lane < n) ? labels[base + 64 + lane] : -1;  // travels while this batch is added
+        unsigned long long m = __ballot(lab == j);
+        while (m != 0) {  // wave-uniform
+            constexpr int G = 4;  // member rows whose loads are in flight together; the adds stay in row order
+            float v0[G], v1[G];
+            int nr = 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                v0[g] = 0.f;
+                v1[g] = 0.f;
+                if (m != 0) {
+                    const int64_t row = base + __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (has0) v0[g] = X[row * d + f0];
+                    if (has1) v1[g] = X[row * d + f1];
+                    nr = g + 1;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g < nr) {
+                    acc0 += v0[g];
+                    acc1 += v1[g];
+                    cnt += 1.0f;
+                }
+            }
+        }
+    }
+    if (has0) sums[(size_t)j * d + f0] = (double)acc0;
+    if (has1) sums[(size_t)j * d + f1] = (double)acc1;
+    if (blockIdx.z == 0 && lane == 0) counts[j] = (double)cnt;
+}
+
 static constexpr size_t ACC_LDS_BYTES = 152 * 1024;
 
 int mtp_launch_accumulate(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums,
-                          double *counts, const int32_t *state, hipStream_t s, MtpBatchStride bs) {
+                          double *counts, const int32_t *state, hipStream_t s, MtpBatchStride bs, int sums_mode) {
     if (n == 0) return MTP_OK;
+    if (sums_mode == MTP_LLOYD_SUMS_SKLEARN_1T) {
+        MTP_REQUIRE(k <= 65535 * 32 && bs.batch <= 65535, "mtp_centroid_sums: k / batch too large for the chain kernel");
+        hipLaunchKernelGGL(k_accumulate_chain, dim3((unsigned)k, (unsigned)bs.batch, (unsigned)((d + 127) / 128)), dim3(64), 0,
+                           s, X, n, d, labels, k, sums, counts, state, bs);
+        MTP_LAUNCH_CHECK();
+        return MTP_OK;
+    }
     if (d % 4 != 0 || (size_t)d * 8 + 4 > ACC_LDS_BYTES) {
         MTP_REQUIRE(bs.batch == 1, "mtp_centroid_sums: batched restarts need d %% 4 == 0");
         const int64_t blocks = (n + 255) / 256;
@@ -193,11 +258,74 @@ __global__ __launch_bounds__(64) void k_mstep_centers(double *red, const float *
     if (staged != nullptr) mtp_write_staged_row(staged, j, d, rn, valid, valid ? c2s : 0.f, threadIdx.x, 64);
 }
 
+// NumPy's float32 pairwise summation (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum; what
+// `(center_shift ** 2).sum()` of sklearn _kmeans.py:722 runs on a contiguous float32 array): fewer than 8
+// elements one after the other; up to 128 with eight accumulators, ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then
+// the n % 8 rest; beyond that the halves (the first a multiple of 8) summed recursively and added.
+// a[i] = shift[i] * shift[i], rounded to float like center_shift ** 2.  Restated in oracle.c (orc_pairwise_sum_f32).
+__device__ inline float pw_leaf_sq(const float *sh, int off, int n) {
+    if (n < 8) {
+        float res = -0.0f;
+        for (int i = 0; i < n; ++i) res += sh[off + i] * sh[off + i];
+        return res;
+    }
+    float r[8];
+    for (int q = 0; q < 8; ++q) r[q] = sh[off + q] * sh[off + q];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int q = 0; q < 8; ++q) r[q] += sh[off + i + q] * sh[off + i + q];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += sh[off + i] * sh[off + i];
+    return res;
+}
+__device__ inline float pairwise_sum_sq_numpy(const float *sh, int n) {
+    struct Frame {
+        int off, n, stage;
+        float left;
+    } st[40];
+    int sp = 0;
+    st[sp++] = Frame{0, n, 0, 0.f};
+    float ret = 0.f;
+    while (sp > 0) {
+        Frame &f = st[sp - 1];
+        if (f.n <= 128) {
+            ret = pw_leaf_sq(sh, f.off, f.n);
+            --sp;
+            continue;
+        }
+        int n2 = f.n / 2;
+        n2 -= n2 % 8;
+        if (f.stage == 0) {
+            f.stage = 1;
+            st[sp++] = Frame{f.off, n2, 0, 0.f};
+        } else if (f.stage == 1) {
+            f.left = ret;
+            f.stage = 2;
+            st[sp++] = Frame{f.off + n2, f.n - n2, 0, 0.f};
+        } else {
+            ret = f.left + ret;
+            --sp;
+        }
+    }
+    return 0.0f + ret;  // np.add.reduce starts from the identity
+}
+
+__global__ void k_pairwise_sumsq(const float *v, int n, float *out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out = pairwise_sum_sq_numpy(v, n);
+}
+
+extern "C" int mtp_pairwise_sumsq_f32(const float *v, int n, float *out, void *stream) {
+    MTP_REQUIRE(v && out && n >= 0, "mtp_pairwise_sumsq: bad arguments");
+    hipLaunchKernelGGL(k_pairwise_sumsq, dim3(1), dim3(64), 0, mtp_stream(stream), v, n, out);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
 // One 1024-thread block per restart: the decision needs every count and shift, and the block then
 // zeroes the reduce buffer for the next iteration (1 MB at K=1024, D=128: 16 waves of 512-byte stores).
 __global__ __launch_bounds__(1024) void k_mstep_flags(double *red, int k, int d, double tol, int max_iter,
                                                       int relocation_done, const float *shift, int32_t *flags,
-                                                      double *red_backup, MtpBatchStride bs) {
+                                                      double *red_backup, MtpBatchStride bs, int sums_mode) {
     __shared__ int scratch[16];
     __shared__ double dsum[16];
     {
@@ -240,6 +368,8 @@ __global__ __launch_bounds__(1024) void k_mstep_flags(double *red, int k, int d,
     if (threadIdx.x == 0) {
         double tot = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += dsum[w];
+        // sklearn's own float32 total in NumPy's order for the bit-exact comparison mode (one thread walks it)
+        if (sums_mode == MTP_LLOYD_SUMS_SKLEARN_1T) tot = (double)pairwise_sum_sq_numpy(shift, k);
         const int it = flags[MTP_FLAG_N_ITER] + 1;
         flags[MTP_FLAG_N_ITER] = it;
         flags[MTP_FLAG_N_EMPTY] = 0;
@@ -258,7 +388,7 @@ __global__ __launch_bounds__(1024) void k_mstep_flags(double *red, int k, int d,
 
 int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d, double tol, int max_iter,
                      int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, double *red_backup,
-                     hipStream_t s, MtpBatchStride bs, int flag_parity) {
+                     hipStream_t s, MtpBatchStride bs, int flag_parity, int sums_mode) {
     const bool mfma = mtp_mfma_dim(d);
     const int rows = mfma ? mtp_n_tiles(k) * 32 : k;
     MTP_REQUIRE(bs.batch == 1 || red_backup == nullptr, "mtp_lloyd_mstep: red_backup is not supported for batched restarts");
@@ -266,7 +396,7 @@ int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d
                        C_new, k, d, relocation_done, mfma ? staged : nullptr, c2, shift, flags, bs, flag_parity);
     MTP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mstep_flags, dim3(bs.batch), dim3(1024), 0, s, red, k, d, tol, max_iter, relocation_done, shift,
-                       flags, red_backup, bs);
+                       flags, red_backup, bs, sums_mode);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
 }
@@ -391,6 +521,54 @@ int mtp_launch_inertia_batched(const float *X, int64_t n, int d, const float *C,
 int mtp_launch_inertia(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
                        float *per_point, hipStream_t s) {
     return mtp_launch_inertia_batched(X, n, d, C, labels, inertia, per_point, 1, 0, 0, s);
+}
+
+// sklearn's own inertia with one thread (_k_means_common.pyx:94-124, float32 input): per point the float
+// _euclidean_dense_dense (groups of four, :16-43), the points added one after the other into a float.  Two launches:
+// the per-point distances (one thread per row and restart), then one wave per restart walking them in row order.
+__global__ __launch_bounds__(256) void k_sqdist_rows(const float *__restrict__ X, int64_t n, int d,
+                                                     const float *__restrict__ C, const int32_t *__restrict__ labels,
+                                                     float *per_point, size_t c_stride, size_t lab_stride) {
+    C += blockIdx.y * c_stride;
+    labels += blockIdx.y * lab_stride;
+    per_point += (size_t)blockIdx.y * (size_t)n;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x)
+        per_point[row] = euclid_sq_sklearn(X + row * d, C + (size_t)labels[row] * d, d);
+}
+
+__global__ __launch_bounds__(64) void k_chain_sum_f32(const float *__restrict__ v, int64_t n, double *out) {
+    v += (size_t)blockIdx.x * (size_t)n;
+    const int lane = threadIdx.x;
+    float acc = 0.f;
+    float nxt = lane < n ? v[lane] : 0.f;
+    for (int64_t base = 0; base < n; base += 64) {
+        const float cur = nxt;
+        nxt = (base + 64 + lane < n) ? v[base + 64 + lane] : 0.f;
+        const int cnt = (int)min((int64_t)64, n - base);
+        if (cnt == 64) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), l));
+        } else {
+            for (int l = 0; l < cnt; ++l) acc += __shfl(cur, l);
+        }
+    }
+    if (lane == 0) out[blockIdx.x] = (double)acc;
+}
+
+int mtp_launch_inertia_chain_f32(const float *X, int64_t n, int d, const float *C, const int32_t *labels, double *inertia,
+                                 float *per_point_scratch, int batch, size_t c_stride, size_t lab_stride, hipStream_t s) {
+    if (batch == 0) return MTP_OK;
+    MTP_REQUIRE(batch >= 1 && batch <= 65535, "mtp_inertia: batch must be in [1, 65535]");
+    if (n > 0) {
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_sqdist_rows, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, s, X, n, d, C, labels,
+                           per_point_scratch, c_stride, lab_stride);
+        MTP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_chain_sum_f32, dim3((unsigned)batch), dim3(64), 0, s, per_point_scratch, n, inertia);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -730,7 +908,7 @@ extern "C" int mtp_far_points_f32(const float *X, int64_t n, int d, const float 
 __global__ __launch_bounds__(256) void k_apply_relocation(double *red, int k, int d, int m,
                                                           const float *__restrict__ far_val,
                                                           const int32_t *__restrict__ far_lab,
-                                                          const float *__restrict__ far_rows) {
+                                                          const float *__restrict__ far_rows, int sums_mode) {
     // single block; sequential over the empty clusters like the reference loop (:197-211).
     // sklearn fixes `empty_clusters = where(weight_in_clusters == 0)` BEFORE the loop (:176): a cluster that
     // loses its only member to a relocation during the loop is not served.  The snapshot is kept in the
@@ -753,7 +931,10 @@ __global__ __launch_bounds__(256) void k_apply_relocation(double *red, int k, in
         if (new_id >= k || old_id < 0) break;  // uniform: no empty cluster / no far point left
         for (int c = threadIdx.x; c < d; c += blockDim.x) {
             const double x = (double)far_rows[(size_t)i * d + c];
-            red[(size_t)old_id * d + c] -= x;
+            if (sums_mode == MTP_LLOYD_SUMS_SKLEARN_1T)  // the sums are float32 values there: subtract in float
+                red[(size_t)old_id * d + c] = (double)((float)red[(size_t)old_id * d + c] - (float)x);
+            else
+                red[(size_t)old_id * d + c] -= x;
             red[(size_t)new_id * d + c] = x;
         }
         __syncthreads();
@@ -767,13 +948,17 @@ __global__ __launch_bounds__(256) void k_apply_relocation(double *red, int k, in
         if (counts[j] == 0.0) counts[j] = 0.0;
 }
 
-extern "C" int mtp_apply_relocation_f32(double *red, int k, int d, int m, const float *far_val, const int32_t *far_lab,
-                                        const float *far_rows, void *stream) {
+int mtp_launch_apply_relocation(double *red, int k, int d, int m, const float *far_val, const int32_t *far_lab,
+                                const float *far_rows, int sums_mode, hipStream_t s) {
     MTP_REQUIRE(red && far_val && far_lab && far_rows && m > 0 && m <= k, "mtp_apply_relocation: bad arguments");
-    hipLaunchKernelGGL(k_apply_relocation, dim3(1), dim3(256), 0, mtp_stream(stream), red, k, d, m, far_val, far_lab,
-                       far_rows);
+    hipLaunchKernelGGL(k_apply_relocation, dim3(1), dim3(256), 0, s, red, k, d, m, far_val, far_lab, far_rows, sums_mode);
     MTP_LAUNCH_CHECK();
     return MTP_OK;
+}
+
+extern "C" int mtp_apply_relocation_f32(double *red, int k, int d, int m, const float *far_val, const int32_t *far_lab,
+                                        const float *far_rows, void *stream) {
+    return mtp_launch_apply_relocation(red, k, d, m, far_val, far_lab, far_rows, 0, mtp_stream(stream));
 }
 
 

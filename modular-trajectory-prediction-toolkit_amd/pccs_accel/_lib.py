@@ -12,6 +12,7 @@ STATE_RUNNING, STATE_STRICT, STATE_TOL, STATE_RELOCATE, STATE_MAXITER = 0, 1, 2,
 FLAG_STATE, FLAG_N_ITER, FLAG_N_EMPTY, FLAG_WORDS = 0, 1, 2, 8
 POT_F64, POT_OPENBLAS = 0, 1  # mtp_accel.h MTP_POT_*
 LLOYD_NO_FINAL_ESTEP = 1
+LLOYD_SUMS_SKLEARN_1T = 2
 
 _vp, _i64, _i32, _f32, _f64, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_double,
                                     ctypes.c_size_t)
@@ -43,9 +44,10 @@ SIGNATURES = {
     "mtp_far_points_scratch_bytes": (_i64, [_i64]),
     "mtp_far_points_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mtp_apply_relocation_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mtp_pairwise_sumsq_f32": (_i32, [_vp, _i32, _vp, _vp]),
     "mtp_far_merge_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mtp_lloyd_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _f64, _i32, _vp, _vp, ctypes.POINTER(ctypes.c_int), _vp,
-                             _sz, _vp]),
+    "mtp_lloyd_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _f64, _i32, _vp, _vp, ctypes.POINTER(ctypes.c_int), _i32,
+                             _vp, _sz, _vp]),
     "mtp_comm_unique_id": (_i32, [_vp]),
     "mtp_comm_create": (_i32, [_i32, _i32, _vp, ctypes.POINTER(_vp)]),
     "mtp_comm_destroy": (_i32, [_vp]),
@@ -54,7 +56,7 @@ SIGNATURES = {
                                      ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float), _i32, _vp, _sz, _vp]),
     "mtp_lloyd_batched_workspace_bytes": (_i64, [_i32, _i32, _i32, _i64]),
     "mtp_lloyd_batched_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _f64, _i32, _vp, _vp,
-                                     ctypes.POINTER(ctypes.c_int), _vp, _sz, _vp]),
+                                     ctypes.POINTER(ctypes.c_int), _i32, _vp, _sz, _vp]),
     "mtp_kpp_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "mtp_kpp_batched_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32]),
     "mtp_kmeans_plusplus_batched_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -34,8 +34,11 @@ def _as_device_f32(data, device=None):
             data = np.array(data).astype(float)  # PCCSNet/utils/utility.py:109-110
         t = torch.from_numpy(np.ascontiguousarray(data))
     if t.dtype == torch.float64:
-        warnings.warn("pccs_accel clusters in float32 (the reference's practical dtype); float64 input is cast",
-                      RuntimeWarning, stacklevel=3)
+        # PCCSNet/utils/utility.py:109-110 turns a non-ndarray into float64 and sklearn then clusters in float64.
+        # The kernels here are float32 (what the reference's own call sites pass: memory.npy is float32); casting
+        # silently would return labels that are not the reference's, so the input is refused.
+        raise TypeError("pccs_accel clusters float32 encodings (what the reference's call sites pass); got float64 -- "
+                        "cast with .astype(np.float32) if float32 clustering is what you want")
     if t.dim() != 2:
         raise ValueError(f"Expected 2D array, got shape {tuple(t.shape)}")
     return t.to(device=device, dtype=torch.float32, copy=True).contiguous()
@@ -88,7 +91,8 @@ def restart_batch(n, d, k, n_init):
 
 
 def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, max_iter=300, tol=1e-4,
-               x_mean=None, check_every=None, batch=None, pot_order="openblas", restarts_out=None, stats_order="numpy"):
+               x_mean=None, check_every=None, batch=None, pot_order="openblas", restarts_out=None, stats_order="numpy",
+               sums="f64"):
     """sklearn ``KMeans(n_clusters, n_init=n_init, init=init).fit(X)`` on one MI355X.
 
     X: float32 device tensor [N, D] (not modified).  ``init``: 'k-means++' or a [K, D] array /
@@ -98,7 +102,12 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
     ``batch``: restarts per launch (default: ``restart_batch``); the result does not depend on it.
     ``stats_order``: float order of the column mean / variance (``tolerance_and_mean``).
     ``pot_order``: summation order of the k-means++ potentials (``seeding``: "openblas" reproduces the
-    reference stack's seeds, "f64" sums in double).  ``restarts_out``: a list that receives one
+    reference stack's seeds, "f64" sums in double).  ``sums``: "f64" (default) -- double centroid sums, independent
+    of the workgroup schedule and of the GPU count, within ~1e-6 of any sklearn run (whose float32 sums depend on
+    its thread scheduling); "sklearn_1t" -- the float32 orders of sklearn on ONE thread (row-order chains per
+    cluster and feature, NumPy's pairwise total shift, float32 inertia chain): together with the defaults of
+    ``stats_order`` and ``pot_order`` the whole fit is then sklearn's under ``threadpool_limits(1)`` bit for bit
+    (fixture G15), at the price of a slower M-step.  ``restarts_out``: a list that receives one
     dict(indices, inertia, n_iter, labels) per restart, in order (tests / diagnostics).
     Returns dict(labels int32 [N] (device), centers float32 [K, D] (device), inertia, n_iter, tol_abs,
     x_mean float32 [D] (device): the column mean the points were centred with).
@@ -151,7 +160,7 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
     if batch is None:
         batch = restart_batch(n, d, n_clusters, n_init)
     if init_is_array:
-        consider(*K.lloyd(Xc, c_init, max_iter=max_iter, tol_abs=tol_abs, check_every=check_every))
+        consider(*K.lloyd(Xc, c_init, max_iter=max_iter, tol_abs=tol_abs, check_every=check_every, sums=sums))
     elif batch <= 1:
         # Lloyd one restart at a time, but the restarts are still SEEDED in groups: with one restart
         # half of the seeding kernel's 16-row candidate tile is empty.  Same seeds as one by one
@@ -162,8 +171,8 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
         for s0 in range(0, n_init, group):
             c0s, idx = seeding.kmeans_plusplus_batched(Xc, n_clusters, draws[s0:s0 + group], pot_order=pot_order)
             for b in range(c0s.shape[0]):
-                consider(*K.lloyd(Xc, c0s[b].contiguous(), max_iter=max_iter, tol_abs=tol_abs, check_every=check_every),
-                         indices=idx[b])
+                consider(*K.lloyd(Xc, c0s[b].contiguous(), max_iter=max_iter, tol_abs=tol_abs, check_every=check_every,
+                                  sums=sums), indices=idx[b])
             del c0s
     else:
         # the draws of every restart, in sklearn's order (seeding consumes the stream, Lloyd does not)
@@ -171,7 +180,7 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
         for s0 in range(0, n_init, batch):
             c0s, idx = seeding.kmeans_plusplus_batched(Xc, n_clusters, draws[s0:s0 + batch], pot_order=pot_order)
             labels, inertia, centers, n_iter = K.lloyd_batched(Xc, c0s, max_iter=max_iter, tol_abs=tol_abs,
-                                                               check_every=check_every or 4)
+                                                               check_every=check_every or 4, sums=sums)
             inertia = inertia.cpu().numpy()
             for b in range(c0s.shape[0]):
                 consider(labels[b], float(inertia[b]), centers[b], n_iter[b], indices=idx[b])

@@ -172,8 +172,18 @@ def inertia(X, C, labels, per_point=False):
     return (out, pp) if per_point else out
 
 
-def lloyd(Xc, C0, max_iter=300, tol_abs=0.0, check_every=None):
-    """Single-GPU sklearn ``_kmeans_single_lloyd`` on centred data.
+def _sums_option(sums):
+    """``sums``: "f64" (default: double centroid sums, schedule-independent) or "sklearn_1t" (float32 row-order
+    chains, NumPy-order total shift, float32 inertia chain: what sklearn computes with one thread, bit for bit)."""
+    if sums in (None, "f64"):
+        return 0
+    if sums == "sklearn_1t":
+        return _lib.LLOYD_SUMS_SKLEARN_1T
+    raise ValueError(f"sums must be 'f64' or 'sklearn_1t', got {sums!r}")
+
+
+def lloyd(Xc, C0, max_iter=300, tol_abs=0.0, check_every=None, sums="f64"):
+    """Single-GPU sklearn ``_kmeans_single_lloyd`` on centred data.  ``sums``: see ``_sums_option``.
 
     Returns (labels int32 [N], inertia float, centers float32 [K, D], n_iter)."""
     _req(Xc, "X", torch.float32, 2)
@@ -195,12 +205,13 @@ def lloyd(Xc, C0, max_iter=300, tol_abs=0.0, check_every=None):
     n_iter = ctypes.c_int(0)
     with torch.cuda.device(Xc.device):
         check(lib().mtp_lloyd_f32(ptr(Xc), n, d, ptr(C), k, int(max_iter), float(tol_abs), int(check_every),
-                                  ptr(labels), ptr(inert), ctypes.byref(n_iter), ptr(ws), ws_bytes, stream_ptr()),
+                                  ptr(labels), ptr(inert), ctypes.byref(n_iter), _sums_option(sums), ptr(ws), ws_bytes,
+                                  stream_ptr()),
               "mtp_lloyd_f32")
     return labels, float(inert.item()), C, int(n_iter.value)
 
 
-def lloyd_batched(Xc, C0s, max_iter=300, tol_abs=0.0, check_every=4):
+def lloyd_batched(Xc, C0s, max_iter=300, tol_abs=0.0, check_every=4, sums="f64"):
     """``C0s.shape[0]`` independent ``lloyd`` runs on the same centred points, sharing every launch
     (the n_init restarts of KMeans.fit).  C0s [B, K, D].  Returns (labels int32 [B, N],
     inertia float64 [B] (device), centers float32 [B, K, D], n_iter list of B ints)."""
@@ -220,7 +231,8 @@ def lloyd_batched(Xc, C0s, max_iter=300, tol_abs=0.0, check_every=4):
     n_iter = (ctypes.c_int * b)()
     with torch.cuda.device(Xc.device):
         check(lib().mtp_lloyd_batched_f32(ptr(Xc), n, d, ptr(C), k, b, int(max_iter), float(tol_abs), int(check_every),
-                                          ptr(labels), ptr(inert), n_iter, ptr(ws), ws_bytes, stream_ptr()),
+                                          ptr(labels), ptr(inert), n_iter, _sums_option(sums), ptr(ws), ws_bytes,
+                                          stream_ptr()),
               "mtp_lloyd_batched_f32")
     return labels, inert, C, [int(v) for v in n_iter]
 

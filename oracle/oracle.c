@@ -198,6 +198,41 @@ double orc_inertia_f32(const float *X, int64_t n, int d, const float *C, const i
     return tot;
 }
 
+/* The same with the points added one after the other into a FLOAT: sklearn's own inertia when it runs on one
+ * thread (_k_means_common.pyx:116-124, `inertia += sq_dist * sample_weight[i]` in the input's float type). */
+double orc_inertia_chain_f32(const float *X, int64_t n, int d, const float *C, const int32_t *labels) {
+    volatile float tot = 0.f; /* volatile: no vectorised re-association */
+    for (int64_t i = 0; i < n; ++i) tot = tot + euclid_sq_f32(X + i * d, C + (size_t)labels[i] * d, d);
+    return (double)tot;
+}
+
+/* NumPy's float32 pairwise summation of v[i] * v[i] (numpy/_core/src/umath/loops_utils.h.src, FLOAT_pairwise_sum;
+ * PW_BLOCKSIZE 128) -- `(center_shift ** 2).sum()` of sklearn cluster/_kmeans.py:722 on a contiguous array:
+ * n < 8 one after the other from -0; n <= 128 eight accumulators, ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the
+ * n % 8 rest; larger n: the two halves (the first a multiple of 8) recursively.  The reduction starts from the
+ * identity 0. */
+static float pw_sumsq(const float *v, int64_t n) {
+    if (n < 8) {
+        float res = -0.0f;
+        for (int64_t i = 0; i < n; ++i) res += v[i] * v[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        int64_t i;
+        for (int q = 0; q < 8; ++q) r[q] = v[q] * v[q];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int q = 0; q < 8; ++q) r[q] += v[i + q] * v[i + q];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += v[i] * v[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return pw_sumsq(v, n2) + pw_sumsq(v + n2, n - n2);
+}
+float orc_pairwise_sumsq_f32(const float *v, int64_t n) { return 0.0f + pw_sumsq(v, n); }
+
 /* PCCSNet/utils/utility.py:98-105 get_modality: per-cluster mean of the member rows.
  * Sum in double, one rounding.  counts[j]==0 leaves the row untouched; the Python side
  * raises KeyError like the reference's dict lookup does. */

@@ -414,14 +414,79 @@ def gen_g14(utility, only=None):
              labels=labels.astype(np.uint8 if K <= 256 else np.uint16), sizes=sizes)
 
 
+def gen_g15(utility, only=None):
+    """G14's six configurations again, with the reference stack held to ONE thread
+    (``threadpool_limits(1)`` around ``np.random.seed(s); utility.cluster_data(X, K)``): sklearn's M-step then adds
+    every cluster's rows in row order into one float32 buffer (_k_means_lloyd.pyx:215-218; the thread-local buffer is
+    added once to zeros), so the whole fit is deterministic -- asserted here by running every restart's Lloyd loop a
+    second time from its recorded seeds -- and the product's ``sums="sklearn_1t"`` mode can be compared with it bit
+    for bit: per restart the k-means++ indices, n_iter, the float32 inertia, a digest and the size histogram of the
+    labels; the winner; the final labels and sizes.  The fixture also records the stack it was made on (OpenBLAS
+    core: the order of the seeding's float32 potentials is that of its sdot / sgemv_t kernels)."""
+    import zlib
+    import sklearn
+    import sklearn.cluster._kmeans as skm
+    from sklearn.cluster import KMeans
+    from threadpoolctl import threadpool_info, threadpool_limits
+
+    info = threadpool_info()
+    blas = [i for i in info if i.get("user_api") == "blas"]
+    stack = "numpy %s; scikit-learn %s; %s" % (np.__version__, sklearn.__version__, "; ".join(
+        "%s %s core=%s" % (i.get("internal_api"), i.get("version"), i.get("architecture")) for i in blas))
+    for name, seed, n, d, k_true, K, spread, noise, np_seed in G14_CASES:
+        name = name.replace("g14_fit_", "g15_fit1t_")
+        if only and name not in only:
+            continue
+        X = datagen.make_encodings(seed, n, d, k_true, spread, noise)
+        rec = dict(idx=[], n_iter=[], inertia=[], crc=[], sizes=[])
+        kpp0, lloyd0 = skm._kmeans_plusplus, skm._kmeans_single_lloyd
+
+        def kpp(*a, **kw):
+            centers, indices = kpp0(*a, **kw)
+            rec["idx"].append(np.asarray(indices, dtype=np.int64).copy())
+            return centers, indices
+
+        def lloyd(*a, **kw):
+            assert kw.get("n_threads", a[-1] if a else None) == 1, "sklearn is not running its Lloyd loop on one thread"
+            labels, inertia, centers, n_iter = lloyd0(*a, **kw)
+            rec["n_iter"].append(n_iter)
+            rec["inertia"].append(np.float64(inertia))
+            rec["crc"].append(zlib.crc32(np.ascontiguousarray(labels, dtype=np.int32).tobytes()))
+            rec["sizes"].append(np.bincount(labels, minlength=K).astype(np.int32))
+            return labels, inertia, centers, n_iter
+
+        with threadpool_limits(limits=1):
+            skm._kmeans_plusplus, skm._kmeans_single_lloyd = kpp, lloyd
+            try:
+                np.random.seed(np_seed)
+                labels, sizes = utility.cluster_data(X.copy(), K)
+            finally:
+                skm._kmeans_plusplus, skm._kmeans_single_lloyd = kpp0, lloyd0
+            assert len(rec["idx"]) == 20 and len(rec["n_iter"]) == 20
+            crc_final = zlib.crc32(np.ascontiguousarray(labels, dtype=np.int32).tobytes())
+            winner = rec["crc"].index(crc_final)
+            # deterministic?  every restart's Lloyd run once more from its recorded seeds
+            for r in range(20):
+                km = KMeans(n_clusters=K, init=X[rec["idx"][r]].copy(), n_init=1).fit(X)
+                assert km.n_iter_ == rec["n_iter"][r], (name, r, km.n_iter_, rec["n_iter"][r])
+                assert zlib.crc32(np.ascontiguousarray(km.labels_, dtype=np.int32).tobytes()) == rec["crc"][r], (name, r)
+                assert np.float64(km.inertia_) == rec["inertia"][r], (name, r)
+        save(name, seed=seed, n=n, d=d, k_true=k_true, K=K, spread=spread, noise=noise, np_seed=np_seed,
+             x_crc=zlib.crc32(X.tobytes()), kpp_indices=np.stack(rec["idx"]), n_iter=np.asarray(rec["n_iter"]),
+             inertia=np.asarray(rec["inertia"]), labels_crc=np.asarray(rec["crc"], dtype=np.int64),
+             restart_sizes=np.stack(rec["sizes"]), winner=winner, stack=np.array(stack),
+             labels=labels.astype(np.uint8 if K <= 256 else np.uint16), sizes=sizes)
+
+
 if __name__ == "__main__":
     warnings.simplefilter("error")  # a ConvergenceWarning here means a bad fixture
     utility, metrics = _import_ref("PCCSNet")
-    only = [a for a in sys.argv[1:] if not a.startswith("g14_")]
+    only = [a for a in sys.argv[1:] if not a.startswith(("g14_", "g15_"))]
     g14_only = [a for a in sys.argv[1:] if a.startswith("g14_")]  # e.g. `gen_golden.py g14 g14_fit_univ_n30128_k200`
+    g15_only = [a for a in sys.argv[1:] if a.startswith("g15_")]
     jobs = dict(g1=lambda: gen_g1(utility), g2=lambda: gen_g2(utility), g45=gen_g4_g5,
                 g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, g13=gen_g13,
-                g14=lambda: gen_g14(utility, g14_only or None))
+                g14=lambda: gen_g14(utility, g14_only or None), g15=lambda: gen_g15(utility, g15_only or None))
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

@@ -15,6 +15,8 @@ What can be asked of such a comparison, and is asserted here:
     close to the boundary between its two centres as sklearn's own re-labelled points are.
   * The product's Lloyd loop IS deterministic (double sums).  Against the oracle run with the same
     documented variant (sums="f64") every restart must agree exactly: n_iter, labels bit for bit.
+  * With ONE thread sklearn is deterministic too, and the product's sums="sklearn_1t" mode reproduces that run
+    bit for bit (fixture G15, test_seeded_fit_bit_equal_to_sklearn_on_one_thread): no allowance at all.
 """
 import zlib
 
@@ -145,7 +147,7 @@ def test_seeded_fit_at_reference_size(name, gpu_device):
           f"{20 - own_iter_moves}/20); restarts with bit-equal labels {sum(d == 0 for d in diffs)}/20; "
           f"largest size-histogram distance {max(diffs)} points (sklearn against itself: up to {own_spread} labels)")
     assert n_iter_equal >= 20 - max(2, 2 * own_iter_moves)
-    assert max(diffs) <= max(4 * own_spread, n // 500)
+    assert max(diffs) <= own_spread          # no further than sklearn moves against itself (bit-exact: the one-thread test below)
 
     # the winner and the final labels
     inert = np.array([r["inertia"] for r in restarts])
@@ -154,7 +156,7 @@ def test_seeded_fit_at_reference_size(name, gpu_device):
     assert np.array_equal(final, labels_gpu[int(g["winner"])])
     want = g["labels"].astype(np.int32)
     mism = np.nonzero(final != want)[0]
-    assert mism.size <= max(4 * own_spread, n // 500), mism.size
+    assert mism.size <= own_spread, mism.size
     if mism.size:
         # Every point labelled differently lies about as close to the boundary between its two centres as the
         # points sklearn re-labels between two runs of its own (rerun_rel_gap).  These are not 1e-6 near-ties:
@@ -168,9 +170,9 @@ def test_seeded_fit_at_reference_size(name, gpu_device):
         rel = np.abs(da - db) / np.maximum(da, db)
         print(f"{name}: final labels differ on {mism.size} of {n} points, relative distance gaps up to {rel.max():.2e} "
               f"(sklearn against itself: up to {own_gap:.2e})")
-        assert rel.max() <= max(3 * own_gap, 1e-3)
+        assert rel.max() <= own_gap
     sizes = np.bincount(final, minlength=K)
-    assert int(np.abs(sizes - g["sizes"]).sum()) <= 2 * max(4 * own_spread, n // 500)
+    assert int(np.abs(sizes - g["sizes"]).sum()) <= 2 * own_spread
 
 
 @pytest.mark.parametrize("name", ["g14_fit_sdd_n17970_k400", "g14_fit_eth_n73568_k200"])
@@ -193,3 +195,82 @@ def test_get_modality_at_reference_size(name, gpu_device):
     mod = get_modality(torch.from_numpy(X), labels, k)
     assert mod.dtype == torch.float32 and tuple(mod.shape) == (k, X.shape[1])
     assert np.allclose(mod.numpy(), O.get_modality(X, labels, k), rtol=1e-6, atol=1e-7)
+
+
+G15_NAMES = ["g15_fit1t_sdd_n17970_k400", "g15_fit1t_eth_n73568_k200", "g15_fit1t_hotel_n76646_k200",
+             "g15_fit1t_univ_n30128_k200", "g15_fit1t_zara1_n74084_k200", "g15_fit1t_zara2_n66976_k200"]
+
+
+@pytest.mark.parametrize("name", G15_NAMES)
+def test_seeded_fit_bit_equal_to_sklearn_on_one_thread(name, gpu_device):
+    """The whole ``np.random.seed(s); cluster_data(X, K)`` of PCCSNet/utils/utility.py:108-133 against the reference
+    stack held to ONE thread (fixture G15: sklearn is deterministic then, asserted by the generator).  With
+    ``sums="sklearn_1t"`` -- float32 row-order chains for the centroid sums (_k_means_lloyd.pyx:215-218), NumPy's
+    pairwise float32 total shift, float32 inertia chain -- nothing is left to tolerate: the seeds, every restart's
+    n_iter / labels / inertia, the winner and the final labels are sklearn's bit for bit.  No spread allowance."""
+    from pccs_accel import clustering
+    g = load_golden(name)
+    X = _g14_inputs(g)
+    K = int(g["K"])
+    restarts = []
+    np.random.seed(int(g["np_seed"]))
+    fit = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), K, n_init=20, restarts_out=restarts, sums="sklearn_1t")
+    assert len(restarts) == 20
+    got_idx = np.stack([r["indices"].cpu().numpy() for r in restarts])
+    assert np.array_equal(got_idx, g["kpp_indices"])
+    for r in range(20):
+        lab = np.ascontiguousarray(restarts[r]["labels"].cpu().numpy(), dtype=np.int32)
+        assert restarts[r]["n_iter"] == int(g["n_iter"][r]), (name, r, restarts[r]["n_iter"], int(g["n_iter"][r]))
+        assert zlib.crc32(lab.tobytes()) == int(g["labels_crc"][r]), \
+            (name, r, int(np.abs(np.bincount(lab, minlength=K) - g["restart_sizes"][r]).sum()) // 2)
+        assert restarts[r]["inertia"] == float(g["inertia"][r]), (name, r, restarts[r]["inertia"], float(g["inertia"][r]))
+    final = fit["labels"].cpu().numpy()
+    assert np.array_equal(final, g["labels"].astype(np.int32))
+    assert np.array_equal(np.bincount(final, minlength=K), g["sizes"])
+    assert fit["inertia"] == float(g["inertia"][int(g["winner"])]) and fit["n_iter"] == int(g["n_iter"][int(g["winner"])])
+    # the restarts one at a time (mtp_lloyd_f32 instead of mtp_lloyd_batched_f32): the same bits
+    if name == G15_NAMES[0]:
+        one = []
+        np.random.seed(int(g["np_seed"]))
+        fit1 = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), K, n_init=20, restarts_out=one, sums="sklearn_1t",
+                                     batch=1)
+        assert torch.equal(fit1["labels"], fit["labels"]) and torch.equal(fit1["centers"], fit["centers"])
+        assert [r["n_iter"] for r in one] == [r["n_iter"] for r in restarts]
+        assert [r["inertia"] for r in one] == [r["inertia"] for r in restarts]
+
+
+@pytest.mark.parametrize("k", [1, 5, 7, 8, 9, 64, 127, 128, 129, 200, 255, 256, 257, 400, 1024, 3001, 8192])
+def test_pairwise_sumsq_in_numpy_order(k, gpu_device):
+    """mtp_pairwise_sumsq_f32 (the total shift of the sklearn_1t mode) against oracle.c's restatement of NumPy's
+    pairwise float32 summation, itself pinned to ``(v ** 2).sum()`` in the CPU suite."""
+    from pccs_accel._lib import check, lib, ptr, stream_ptr
+    rs = np.random.RandomState(k)
+    for scale in (1.0, 1e-3):
+        v = (rs.rand(k) * scale * 10.0 ** rs.uniform(-2, 2, size=k)).astype(np.float32)
+        out = torch.zeros(1, dtype=torch.float32, device=gpu_device)
+        vd = torch.from_numpy(v).to(gpu_device)
+        check(lib().mtp_pairwise_sumsq_f32(ptr(vd), k, ptr(out), stream_ptr()), "mtp_pairwise_sumsq_f32")
+        got = out.cpu().numpy()[0]
+        assert got.view(np.uint32) == O.pairwise_sumsq_f32(v).view(np.uint32), (k, got, O.pairwise_sumsq_f32(v))
+
+
+def test_one_thread_mode_with_relocation_and_generic_d(gpu_device):
+    """sums="sklearn_1t" off the beaten path, against the oracle's one-thread restatement (sums="f32", which the CPU
+    suite pins to G15): an unreachable centre (relocation in float arithmetic), d = 128 and d = 64, and a feature
+    size without an MFMA instantiation (d = 20: generic E-step, chain kernel with idle lanes)."""
+    from pccs_accel import kernels as K
+    for seed, n, d, k, bad in [(301, 3000, 96, 12, 5), (302, 2500, 128, 33, None), (303, 2047, 64, 17, 2),
+                               (304, 1500, 20, 9, None), (305, 900, 200, 6, 1)]:
+        X = datagen.make_encodings(seed, n, d, 10, 2000, 600)
+        Xc = np.ascontiguousarray(X - X.mean(axis=0))
+        C0 = Xc[datagen.make_init_indices(seed + 1, n, k)].copy()
+        if bad is not None:
+            C0[bad] = 50.0
+        tol = float(O.tolerance(X))
+        ol, oi, oc, on = O.kmeans_single_lloyd(Xc, C0, 300, tol, sums="f32", far_order="descending", inertia_order="f32_chain")
+        labels, inertia, centers, n_iter = K.lloyd(torch.from_numpy(Xc).to(gpu_device), torch.from_numpy(C0).to(gpu_device),
+                                                   tol_abs=tol, sums="sklearn_1t")
+        assert n_iter == on, (seed, n_iter, on)
+        assert np.array_equal(labels.cpu().numpy(), ol), seed
+        assert np.array_equal(centers.cpu().numpy().view(np.uint32), oc.view(np.uint32)), seed
+        assert inertia == oi, (seed, inertia, oi)
