@@ -70,15 +70,16 @@ __global__ __launch_bounds__(256) void k_assign_generic(const float *__restrict_
 // Stage C [k, d] -> staged image + c2 (einsum order).  One block per (padded) centroid row.
 __global__ __launch_bounds__(64) void k_stage_centers(const float *__restrict__ C, int k, int d, float *staged,
                                                       float *c2, const int32_t *state, MtpBatchStride bs) {
+    const int j = blockIdx.x;
+    int img_row = j;
     {
         const size_t b = blockIdx.y;
         C += b * bs.c0;
-        if (staged != nullptr) staged += b * bs.staged;
+        if (staged != nullptr) staged = mtp_image_of(staged, bs, b, j, &img_row);
         if (c2 != nullptr) c2 += b * bs.kvec;
         if (state != nullptr) state += b * bs.flags;
     }
     if (state != nullptr && *state != MTP_STATE_RUNNING) return;
-    const int j = blockIdx.x;
     const bool valid = j < k;
     __shared__ float c2s;
     if (threadIdx.x == 0) {
@@ -86,13 +87,27 @@ __global__ __launch_bounds__(64) void k_stage_centers(const float *__restrict__ 
         if (valid && c2 != nullptr) c2[j] = c2s;
     }
     __syncthreads();
-    if (staged != nullptr) mtp_write_staged_row(staged, j, d, C + (size_t)(valid ? j : 0) * d, valid, c2s, threadIdx.x, 64);
+    if (staged != nullptr) mtp_write_staged_row(staged, img_row, d, C + (size_t)(valid ? j : 0) * d, valid, c2s, threadIdx.x, 64);
+}
+
+// Grouped images: every row invalid (zeros, ||c||^2 = +inf) before the restarts' rows are staged, so that the rows
+// between k and kp of a restart and the rows behind the last restart of a group never win.  One block per image row.
+__global__ __launch_bounds__(64) void k_clear_images(float *images, int d, size_t image_floats) {
+    float *img = images + (size_t)blockIdx.y * image_floats;
+    mtp_write_staged_row(img, blockIdx.x, d, nullptr, false, 0.f, threadIdx.x, 64);
+}
+
+int mtp_launch_clear_images(float *images, int n_images, int tiles, int d, size_t image_floats, hipStream_t s) {
+    hipLaunchKernelGGL(k_clear_images, dim3(tiles * 32, n_images), dim3(64), 0, s, images, d, image_floats);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
 }
 
 int mtp_launch_stage_centers(const float *C, int k, int d, float *staged, float *c2, const int32_t *state,
                              hipStream_t s, MtpBatchStride bs) {
     const bool mfma = mtp_mfma_dim(d);
-    const int rows = mfma ? mtp_n_tiles(k) * 32 : k;
+    // grouped images: only the k valid rows (the rest was cleared once by mtp_launch_clear_images)
+    const int rows = bs.group_r > 0 ? k : (mfma ? mtp_n_tiles(k) * 32 : k);
     hipLaunchKernelGGL(k_stage_centers, dim3(rows, bs.batch), dim3(64), 0, s, C, k, d, mfma ? staged : nullptr, c2,
                        state, bs);
     MTP_LAUNCH_CHECK();
@@ -153,9 +168,57 @@ static int launch_assign_mfma(const float *X, int64_t n, const float *staged, in
     return launch_assign_mfma_wpb<D, 16>(Xt, n_tail, staged, k, lt, n_changed, state, s, bs);
 }
 
+template <int D>
+static int launch_assign_grouped(const float *X, int64_t n, const float *images, int32_t *labels, double *n_changed,
+                                 const int32_t *state, hipStream_t s, MtpBatchStride bs) {
+    constexpr int WPB = 8;
+    const int group_tiles = (bs.group_r * bs.kp + 31) / 32;
+    MTP_REQUIRE(group_tiles <= 64 && bs.group_r <= 8, "mtp_assign: restart group too large (%d restarts, %d tiles)", bs.group_r,
+                group_tiles);
+    const size_t lds = 2 * (size_t)2 * mtp_tile_floats(D) * sizeof(float);
+    MTP_SET_MAX_LDS_ONCE((&k_assign_mfma_grouped<D, WPB>), lds);
+    const int64_t blocks = (n + WPB * 32 - 1) / (WPB * 32);
+    const int n_groups = (bs.batch + bs.group_r - 1) / bs.group_r;
+    MTP_REQUIRE(blocks <= 0x7fffffff && n_groups <= 65535, "mtp_assign: n too large");
+    hipLaunchKernelGGL((k_assign_mfma_grouped<D, WPB>), dim3((unsigned)blocks, (unsigned)n_groups), dim3(64 * WPB), lds, s, X, n,
+                       images, bs.kp, bs.group_r, group_tiles, bs.image_floats, labels, n_changed, state, bs);
+    MTP_LAUNCH_CHECK();
+    return MTP_OK;
+}
+
+// How many restarts share a centroid image (mtp_lloyd_batched_f32).  One round = 2 workgroups on every CU; a launch
+// costs rounds x (tiles per group + the fixed costs of a workgroup, ~2 tiles' worth).  0: one image per restart.
+int mtp_pick_restart_group(int64_t n, int k, int batch, int cus) {
+    if (batch < 2) return 0;
+    const int kp = (k + 7) / 8 * 8;
+    const double blocks = (double)((n + 255) / 256);
+    int best_r = 0;
+    double best_cost = 0.0;
+    for (int r = 1; r <= batch && r <= 8; ++r) {
+        const int tiles = r == 1 ? (k + 31) / 32 : (r * kp + 31) / 32;
+        if (tiles > 64) break;
+        const int groups = (batch + r - 1) / r;
+        const double rounds = blocks * groups / (2.0 * cus);
+        const double cost = (rounds < 1.0 ? 1.0 : (double)(int64_t)(rounds + 0.999)) * (tiles + 2.0);
+        if (best_r == 0 || cost < best_cost * 0.97) {  // a larger group must pay for itself
+            best_r = r;
+            best_cost = cost;
+        }
+    }
+    return best_r <= 1 ? 0 : best_r;
+}
+
 int mtp_launch_assign(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2, int k,
                       int32_t *labels, double *n_changed, const int32_t *state, hipStream_t s, MtpBatchStride bs) {
     if (n == 0) return MTP_OK;
+    if (bs.group_r > 0) {
+        MTP_REQUIRE(mtp_mfma_dim(d) && staged != nullptr, "mtp_assign: grouped restarts need d in {64, 96, 128} and the images");
+        switch (d) {
+            case 64: return launch_assign_grouped<64>(X, n, staged, labels, n_changed, state, s, bs);
+            case 96: return launch_assign_grouped<96>(X, n, staged, labels, n_changed, state, s, bs);
+            default: return launch_assign_grouped<128>(X, n, staged, labels, n_changed, state, s, bs);
+        }
+    }
     MTP_REQUIRE(bs.batch == 1 || mtp_mfma_dim(d), "mtp_assign: batched restarts need d in {64, 96, 128} (got %d)", d);
     if (mtp_mfma_dim(d)) {
         MTP_REQUIRE(staged != nullptr, "mtp_assign: staged centroid image missing for d=%d", d);

@@ -250,3 +250,212 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_assign_mfma(const float *__re
         if (lane == 0 && changed != 0) atomicAdd(n_changed, (double)changed);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Restart-grouped E-step for the batched fit (KMeans(K, n_init=20) at the reference's K = 200 / 400).
+//
+// With one restart per workgroup (k_assign_mfma, blockIdx.y = restart) a workgroup at K = 200 lives for 7 centroid
+// tiles, an eighth of which (24 of 224 rows) is padding, and its fixed costs -- fetching its points, the first
+// centroid stage, the closing label write -- are paid once per 7 tiles.  Here a workgroup keeps its points in
+// registers and scores them against a GROUP of R restarts whose centres form ONE image: row r * kp + j is centre
+// j of the group's r-th restart (kp = k rounded up to 8).  R * kp rows are ceil(R * kp / 32) tiles -- 25 for
+// R = 4, K = 200, no padding at all -- and the fixed costs are paid once per group.  A restart boundary falls on a
+// multiple of 8 rows, which in the 32x32 accumulator layout is a boundary between register quads (rows 8q .. 8q+7
+// are registers 4q .. 4q+3 of both lane halves): the running argmin is closed and re-opened between two quads,
+// uniformly for the whole wave.  The arithmetic per (point, centroid) and the ascending order of the comparisons
+// within a restart are those of k_assign_mfma: same labels (tests/test_gpu_batched.py compares the two).
+// Restarts that have stopped keep their rows in the image; tiles that hold only such rows are skipped (no DMA, no
+// MFMA), a tile shared with a live restart is computed and the stopped restart's quads ignored.
+// ------------------------------------------------------------------------------------------
+template <int D, int WPB>
+__global__ __launch_bounds__(64 * WPB, 4) void k_assign_mfma_grouped(const float *__restrict__ X, int64_t n,
+                                                                    const float *__restrict__ images, int kp, int R,
+                                                                    int group_tiles, size_t image_floats,
+                                                                    int32_t *__restrict__ labels, double *n_changed,
+                                                                    const int32_t *state, MtpBatchStride bs) {
+    constexpr int CTW = 2;
+    constexpr int RS = D / 4;                  // 16-byte slots per centroid row
+    constexpr int TILE_F = 32 * (D + 4) + 32;
+    constexpr int STAGE_F = CTW * TILE_F;
+    constexpr int STAGE_SLOTS = STAGE_F / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * STAGE_F floats
+
+    const int b0 = blockIdx.y * R;                                  // first restart of this group
+    const int rg = min(R, bs.batch - b0);                           // restarts in this group
+    const float *staged = images + (size_t)blockIdx.y * image_floats;
+    unsigned live = 0;                                              // wave-uniform: bit r = restart b0 + r still runs
+    for (int r = 0; r < rg; ++r)
+        if (!mtp_skip(state != nullptr ? state + (size_t)(b0 + r) * bs.flags : nullptr, bs.skip_mode)) live |= 1u << r;
+    if (live == 0) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t pbase = ((int64_t)blockIdx.x * WPB + wave) * 32;
+    const int64_t row = min(pbase + j, n - 1);  // tail rows are computed and discarded
+
+    // a tile is worth computing if one of the restarts with rows in it is live: bit `tile` of tmask (the host keeps
+    // group_tiles <= 64).  Walked restart by restart, no division.
+    unsigned long long tmask = 0;
+    for (int r = 0, lo = 0; r < rg; ++r, lo += kp) {
+        if (!((live >> r) & 1u)) continue;
+        const int t_lo = lo >> 5, t_hi = (lo + kp - 1) >> 5;
+        tmask |= (t_hi - t_lo >= 63 ? ~0ull : ((1ull << (t_hi - t_lo + 1)) - 1)) << t_lo;
+    }
+    auto tile_live = [&](int tile) -> bool { return tile < group_tiles && ((tmask >> tile) & 1ull); };
+    const int n_stages = (group_tiles + CTW - 1) / CTW;
+    auto next_live_stage = [&](int t) -> int {
+        while (t < n_stages && !(tile_live(CTW * t) || tile_live(CTW * t + 1))) ++t;
+        return t;
+    };
+    const int wave_slot0 = wave * 64;
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    auto stage = [&](int t, int buf) {
+        const float *g = staged + (size_t)t * STAGE_F;
+        const unsigned l = smem_base + (unsigned)(buf * STAGE_F * 4);
+        for (int s0 = wave_slot0; s0 < STAGE_SLOTS; s0 += 64 * WPB) {
+            if (s0 + lane < STAGE_SLOTS)
+                glds16(g + (size_t)(s0 + lane) * 4, __builtin_amdgcn_readfirstlane(l + (unsigned)s0 * 16));
+        }
+    };
+    int t = next_live_stage(0);
+    int buf = 0;
+    stage(t, buf);  // the first centroid stage travels while the points are fetched
+
+    // The label of the iteration before is only compared when a restart is closed.  It is requested one restart
+    // ahead -- the first live restart's here, the next live one's each time a restart is closed -- so that a close
+    // does not wait for memory (the stage loop's vmcnt(0) waits have long covered the load by then).
+    auto next_live_restart = [&](int r) -> int {
+        while (r < rg && !((live >> r) & 1u)) ++r;
+        return r;
+    };
+    int old_r = next_live_restart(0);  // the restart old_lab belongs to (uniform)
+    int old_lab = (n_changed != nullptr && old_r < rg) ? labels[(size_t)(b0 + old_r) * bs.labels + row] : -1;
+
+    // B operands: this wave's 32 points, as in k_assign_mfma (each half fetches every second 16-byte slot, the halves
+    // trade with v_permlane32_swap)
+    constexpr int SLOTS = D / 8;
+    constexpr int SG = SLOTS <= 12 ? SLOTS : 8;
+    static_assert(SLOTS % SG == 0, "slot groups");
+    float xr[D / 2];
+    {
+        const float4 *xp = reinterpret_cast<const float4 *>(X + row * D);
+#pragma unroll
+        for (int m0 = 0; m0 < SLOTS; m0 += SG) {
+            float4 v[SG];
+#pragma unroll
+            for (int g = 0; g < SG; ++g) v[g] = xp[2 * (m0 + g) + h];
+#pragma unroll
+            for (int g = 0; g < SG; ++g) {
+                const int m = m0 + g;
+                const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g].x), __float_as_uint(v[g].y), false, false);
+                const auto zw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g].z), __float_as_uint(v[g].w), false, false);
+                xr[4 * m + 0] = __uint_as_float(xy[0]);
+                xr[4 * m + 1] = __uint_as_float(zw[0]);
+                xr[4 * m + 2] = __uint_as_float(xy[1]);
+                xr[4 * m + 3] = __uint_as_float(zw[1]);
+            }
+        }
+    }
+
+    float best = __builtin_inff();
+    int breg = 0, btile = 0;
+    int cur_r = 0;          // restart whose rows are being compared (uniform)
+    int cur_end = kp;       // first image row of the next restart
+    bool open = false;      // rows of cur_r have been compared
+
+    // close restart r: merge the lane halves (lexicographic (dist, index) minimum = sklearn's strict '<' / first
+    // index), write the labels, count the changed ones
+    auto close_restart = [&](int r) {
+        const int mine = btile * 32 + (breg & 3) + 8 * (breg >> 2) + 4 * h - r * kp;
+        const float ob = __shfl_xor(best, 32);
+        const int oi = __shfl_xor(mine, 32);
+        const bool take = (ob < best) || (ob == best && oi < mine);
+        const int lab = take ? oi : mine;
+        int32_t *lp = labels + (size_t)(b0 + r) * bs.labels;
+        const bool mine_to_write = h == 0 && pbase + j < n;
+        if (mine_to_write) lp[pbase + j] = lab;
+        if (n_changed != nullptr) {  // r == old_r: restarts are closed in ascending order, live ones only
+            const int changed = __builtin_popcountll(__ballot(mine_to_write && old_lab != lab));
+            if (lane == 0 && changed != 0) atomicAdd(n_changed + (size_t)(b0 + r) * bs.red, (double)changed);
+            old_r = next_live_restart(r + 1);
+            if (old_r < rg) old_lab = labels[(size_t)(b0 + old_r) * bs.labels + row];
+        }
+    };
+
+    while (t < n_stages) {
+        const int t_next = next_live_stage(t + 1);
+        dma_wait();       // this wave's share of the stage has landed ...
+        __syncthreads();  // ... and so has everyone else's; all waves are done with the other buffer
+        if (t_next < n_stages) stage(t_next, buf ^ 1);
+        const float *sb = smem + buf * STAGE_F;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            const int tile = t * CTW + ct;
+            if (!tile_live(tile)) continue;  // uniform
+            const float *tb = sb + ct * TILE_F;
+            const float4 *arow = reinterpret_cast<const float4 *>(tb) + j * (RS + 1) + h;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            float4 a = arow[0];
+            {
+                static_assert((D / 8) % 2 == 0, "u-steps are taken two at a time");
+                float4 b = a;
+#pragma unroll
+                for (int u = 0; u < D / 8; u += 2) {
+                    b = arow[2 * (u + 1)];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xr[4 * u + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xr[4 * u + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xr[4 * u + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xr[4 * u + 3], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u + 2 < D / 8) a = arow[2 * (u + 2)];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, xr[4 * u + 4], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, xr[4 * u + 5], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, xr[4 * u + 6], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, xr[4 * u + 7], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // epilogue: d = c2 - 2*dot (one rounding), strict '<' in ascending row order; between two register quads
+            // (8 image rows) the restart may change
+            float before = best;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rowbase = tile * 32 + 8 * g;
+                if (rowbase >= cur_end) {  // uniform, at most once per restart
+                    btile = (best < before) ? tile : btile;
+                    while (rowbase >= cur_end) {
+                        if (open) close_restart(cur_r);
+                        open = false;
+                        ++cur_r;
+                        cur_end += kp;
+                    }
+                    best = __builtin_inff();
+                    breg = 0;
+                    btile = 0;
+                    before = best;
+                }
+                if (cur_r < rg && ((live >> cur_r) & 1u)) {
+                    open = true;
+                    const float4 c2v = *reinterpret_cast<const float4 *>(tb + 32 * (D + 4) + 8 * g + 4 * h);
+                    const float c2a[4] = {c2v.x, c2v.y, c2v.z, c2v.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dist = fmaf(-2.0f, acc[4 * g + r], c2a[r]);
+                        const bool lt = dist < best;
+                        best = lt ? dist : best;
+                        breg = lt ? (4 * g + r) : breg;
+                    }
+                }
+            }
+            btile = (best < before) ? tile : btile;
+        }
+        t = t_next;
+        buf ^= 1;
+    }
+    if (open) close_restart(cur_r);
+}

@@ -637,12 +637,22 @@ extern "C" int mtp_lloyd_sharded_f32(const mtp_comm *comm, const float *X_local,
 // restarts share each launch (blockIdx.y / .z = restart), keep their own loop state and stop
 // on their own.  At reference scale (N ~ 7e4, K = 200) one restart cannot fill the GPU and an
 // iteration is launch-bound; 20 restarts per launch are what makes the fit fast.
+// the restart-grouped centroid images (k_assign_mfma_grouped), whatever the grouping: ceil(batch / R) images of
+// ceil(R * kp / 32) tiles rounded up to 2, an image holding at most 64 tiles -- bounded by
+// batch * (ceil(kp / 32) + 2) + 66 tiles
+static size_t batched_image_bytes(int k, int d, int batch) {
+    if (!mtp_mfma_dim(d)) return 0;
+    const int kp = (k + 7) / 8 * 8;
+    return align_up(((size_t)batch * (size_t)((kp + 31) / 32 + 2) + 66) * mtp_tile_floats(d) * 4, 256);
+}
+
 extern "C" int64_t mtp_lloyd_batched_workspace_bytes(int k, int d, int batch, int64_t n) {
     if (k <= 0 || d <= 0 || batch <= 0 || n < 0) return 0;
     // per restart the Lloyd buffers; the far-point scratch; the packed flags; batch * n floats of per-point distances
     // (the float32 inertia chains of MTP_LLOYD_SUMS_SKLEARN_1T)
     return (int64_t)(carve_lloyd(nullptr, k, d).bytes * (size_t)batch + (size_t)mtp_far_points_scratch_bytes(n) +
-                     align_up((size_t)batch * MTP_FLAG_WORDS * 4, 256) + align_up((size_t)batch * (size_t)n * 4, 256));
+                     align_up((size_t)batch * MTP_FLAG_WORDS * 4, 256) + align_up((size_t)batch * (size_t)n * 4, 256) +
+                     batched_image_bytes(k, d, batch));
 }
 
 // the restarts' flag words, gathered into one contiguous block for a single plain copy to the host
@@ -668,11 +678,25 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
     float *dist_scratch = reinterpret_cast<float *>(static_cast<char *>(ws) + w.bytes * (size_t)batch);
     int32_t *flags_packed = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(dist_scratch) + (size_t)mtp_far_points_scratch_bytes(n));
     float *per_point = reinterpret_cast<float *>(reinterpret_cast<char *>(flags_packed) + align_up((size_t)batch * MTP_FLAG_WORDS * 4, 256));
+    float *images = reinterpret_cast<float *>(reinterpret_cast<char *>(per_point) + align_up((size_t)batch * (size_t)n * 4, 256));
     const int sums_mode = options & MTP_LLOYD_SUMS_SKLEARN_1T;
     MTP_REQUIRE(sums_mode == 0 || k <= 8192, "mtp_lloyd_batched: MTP_LLOYD_SUMS_SKLEARN_1T supports k <= 8192, got k = %d", k);
     hipStream_t s = mtp_stream(stream);
     if (check_every < 1) check_every = 1;
-    MtpBatchStride bs;
+    // restarts that share a centroid image and a workgroup (assign_kernel.h, k_assign_mfma_grouped); MTP_RESTART_GROUP
+    // overrides the choice (0 / 1: one image per restart) -- the labels do not depend on it
+    int cus = 0;
+    if (const int r = mtp_device_cu_count(&cus)) return r;
+    int group_r = mtp_pick_restart_group(n, k, batch, cus);
+    if (const char *e = getenv("MTP_RESTART_GROUP")) {
+        group_r = atoi(e);
+        if (group_r <= 1) group_r = 0;
+        if (group_r > batch) group_r = batch;
+        if (group_r > 8) group_r = 8;
+        while (group_r > 1 && (group_r * ((k + 7) / 8 * 8) + 31) / 32 > 64) --group_r;
+        if (group_r <= 1) group_r = 0;
+    }
+    MtpBatchStride bs = mtp_no_batch();
     bs.staged = w.bytes / 4;
     bs.labels = (size_t)n;
     bs.red = w.bytes / 8;
@@ -682,12 +706,24 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
     bs.kvec = w.bytes / 4;
     bs.skip_mode = 0;
     bs.batch = batch;
+    float *staged = w.staged;  // what the E-step / M-step kernels get as `staged`: restart 0's image, or the group images
+    if (group_r > 0) {
+        bs.group_r = group_r;
+        bs.kp = (k + 7) / 8 * 8;
+        const int tiles = ((group_r * bs.kp + 31) / 32 + 1) / 2 * 2;  // whole 2-tile stages
+        bs.image_floats = (size_t)tiles * mtp_tile_floats(d);
+        const int n_groups = (batch + group_r - 1) / group_r;
+        MTP_REQUIRE((size_t)n_groups * bs.image_floats * 4 <= batched_image_bytes(k, d, batch), "mtp_lloyd_batched: image area (internal error)");
+        staged = images;
+        int rci = mtp_launch_clear_images(images, n_groups, tiles, d, bs.image_floats, s);
+        if (rci != MTP_OK) return rci;
+    }
     auto at = [&](auto *p, int b) { return reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + w.bytes * (size_t)b); };
 
     // begin: zero red + flags of every restart, stage the initial centres, labels_old = -1
     MTP_HIP(hipMemset2DAsync(w.red, w.bytes, 0, (size_t)mtp_red_len(k, d) * 8, batch, s));
     MTP_HIP(hipMemset2DAsync(w.flags, w.bytes, 0, MTP_FLAG_WORDS * 4, batch, s));
-    int rc = mtp_launch_stage_centers(C_inout, k, d, w.staged, w.c2, nullptr, s, bs);
+    int rc = mtp_launch_stage_centers(C_inout, k, d, staged, w.c2, nullptr, s, bs);
     if (rc != MTP_OK) return rc;
     MTP_HIP(hipMemsetAsync(labels_out, 0xff, (size_t)n * 4 * batch, s));
 
@@ -706,11 +742,11 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
         MTP_REQUIRE(round < max_rounds, "mtp_lloyd_batched: the restarts did not finish (internal error)");
         for (int i = 0; i < check_every; ++i) {
             // centres of a restart: buffer (n_iter & 1); the MFMA E-step only reads the staged image
-            rc = mtp_launch_assign(X, n, d, nullptr, w.staged, w.c2, k, labels_out, w.red + (size_t)k * d + k, w.flags, s, bs);
+            rc = mtp_launch_assign(X, n, d, nullptr, staged, w.c2, k, labels_out, w.red + (size_t)k * d + k, w.flags, s, bs);
             if (rc != MTP_OK) return rc;
             rc = mtp_launch_accumulate(X, n, d, labels_out, k, w.red, w.red + (size_t)k * d, w.flags, s, bs, sums_mode);
             if (rc != MTP_OK) return rc;
-            rc = mtp_launch_mstep(w.red, C_inout, w.c_alt, k, d, tol_abs, max_iter, 0, w.staged, w.c2, w.shift, w.flags,
+            rc = mtp_launch_mstep(w.red, C_inout, w.c_alt, k, d, tol_abs, max_iter, 0, staged, w.c2, w.shift, w.flags,
                                   nullptr, s, bs, 1, sums_mode);
             if (rc != MTP_OK) return rc;
         }
@@ -733,8 +769,9 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
                 MTP_HIP(hipMemsetAsync(at(w.flags, b) + MTP_FLAG_STATE, 0, 4, s));
                 MtpBatchStride one = bs;
                 one.batch = 1;
-                rc = mtp_launch_mstep(at(w.red, b), c0, c1, k, d, tol_abs, max_iter, 1, at(w.staged, b), at(w.c2, b),
-                                      at(w.shift, b), at(w.flags, b), nullptr, s, one, 1, sums_mode);
+                one.b_first = b;  // grouped images: the restart's rows sit in its group's image
+                rc = mtp_launch_mstep(at(w.red, b), c0, c1, k, d, tol_abs, max_iter, 1, group_r > 0 ? staged : at(w.staged, b),
+                                      at(w.c2, b), at(w.shift, b), at(w.flags, b), nullptr, s, one, 1, sums_mode);
                 if (rc != MTP_OK) return rc;
                 any_live = true;
             } else if (f[MTP_FLAG_STATE] == MTP_STATE_RUNNING) {
@@ -752,7 +789,7 @@ extern "C" int mtp_lloyd_batched_f32(const float *X, int64_t n, int d, float *C_
     // "labels unchanged" (_kmeans.py:736-748); staged already describes the final centres
     MtpBatchStride fin = bs;
     fin.skip_mode = 1;
-    rc = mtp_launch_assign(X, n, d, nullptr, w.staged, w.c2, k, labels_out, nullptr, w.flags, s, fin);
+    rc = mtp_launch_assign(X, n, d, nullptr, staged, w.c2, k, labels_out, nullptr, w.flags, s, fin);
     if (rc != MTP_OK) return rc;
     if (inertia_out != nullptr) MTP_HIP(hipMemsetAsync(inertia_out, 0, 8 * (size_t)batch, s));
     for (int b = 0; b < batch; ++b) {

@@ -95,8 +95,26 @@ struct MtpBatchStride {
     size_t kvec;    // floats: c2 / shift arrays
     int skip_mode;
     int batch;
+    // Restart-grouped centroid images (k_assign_mfma_grouped): group_r > 0 -> restart b's centre j is row
+    // (b % group_r) * kp + j of the image of group b / group_r; the images are image_floats apart and `staged`
+    // points at the first.  group_r == 0: one image per restart, `staged` strided by .staged.
+    int group_r;
+    int kp;
+    size_t image_floats;
+    int b_first;  // restart index of blockIdx 0 for the image lookup (a single restart of a batch handled alone)
 };
-static inline MtpBatchStride mtp_no_batch() { return MtpBatchStride{0, 0, 0, 0, 0, 0, 0, 0, 1}; }
+static inline MtpBatchStride mtp_no_batch() { return MtpBatchStride{0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0}; }
+
+// where restart b's centre j goes: (image base, row within the image)
+__device__ __forceinline__ float *mtp_image_of(float *staged, const MtpBatchStride &bs, size_t b, int j, int *row) {
+    if (bs.group_r > 0) {
+        b += (size_t)bs.b_first;
+        *row = (int)(b % (size_t)bs.group_r) * bs.kp + j;
+        return staged + (b / (size_t)bs.group_r) * bs.image_floats;
+    }
+    *row = j;
+    return staged + b * bs.staged;
+}
 
 __device__ __forceinline__ bool mtp_skip(const int32_t *state, int skip_mode) {
     if (state == nullptr) return false;
@@ -109,6 +127,8 @@ static inline hipStream_t mtp_stream(void *s) { return reinterpret_cast<hipStrea
 // ---- launchers implemented across the .hip files (all enqueue only) ----
 int mtp_launch_stage_centers(const float *C, int k, int d, float *staged, float *c2, const int32_t *state,
                              hipStream_t s, MtpBatchStride bs = mtp_no_batch());
+int mtp_launch_clear_images(float *images, int n_images, int tiles, int d, size_t image_floats, hipStream_t s);
+int mtp_pick_restart_group(int64_t n, int k, int batch, int cus);
 int mtp_launch_assign(const float *X, int64_t n, int d, const float *C, const float *staged, const float *c2, int k,
                       int32_t *labels, double *n_changed, const int32_t *state, hipStream_t s,
                       MtpBatchStride bs = mtp_no_batch());

@@ -205,11 +205,12 @@ __global__ __launch_bounds__(64) void k_mstep_centers(double *red, const float *
                                                       int flag_parity) {
     extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // 2*d floats: new row, old row
     __shared__ int scratch[2];
+    int img_row = blockIdx.x;
     {
         const size_t b = blockIdx.y;
         red += b * bs.red;
         flags += b * bs.flags;
-        if (staged != nullptr) staged += b * bs.staged;
+        if (staged != nullptr) staged = mtp_image_of(staged, bs, b, (int)blockIdx.x, &img_row);
         c2 += b * bs.kvec;
         shift += b * bs.kvec;
         const float *c0 = C_old + b * bs.c0;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64) void k_mstep_centers(double *red, const float *
         for (int c = threadIdx.x; c < d; c += 64) C_new[(size_t)j * d + c] = rn[c];
     }
     __syncthreads();
-    if (staged != nullptr) mtp_write_staged_row(staged, j, d, rn, valid, valid ? c2s : 0.f, threadIdx.x, 64);
+    if (staged != nullptr) mtp_write_staged_row(staged, img_row, d, rn, valid, valid ? c2s : 0.f, threadIdx.x, 64);
 }
 
 // NumPy's float32 pairwise summation (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum; what
@@ -390,7 +391,7 @@ int mtp_launch_mstep(double *red, const float *C_old, float *C_new, int k, int d
                      int relocation_done, float *staged, float *c2, float *shift, int32_t *flags, double *red_backup,
                      hipStream_t s, MtpBatchStride bs, int flag_parity, int sums_mode) {
     const bool mfma = mtp_mfma_dim(d);
-    const int rows = mfma ? mtp_n_tiles(k) * 32 : k;
+    const int rows = bs.group_r > 0 ? k : (mfma ? mtp_n_tiles(k) * 32 : k);  // grouped images: valid rows only
     MTP_REQUIRE(bs.batch == 1 || red_backup == nullptr, "mtp_lloyd_mstep: red_backup is not supported for batched restarts");
     hipLaunchKernelGGL(k_mstep_centers, dim3(rows, bs.batch), dim3(64), 2 * (size_t)d * sizeof(float), s, red, C_old,
                        C_new, k, d, relocation_done, mfma ? staged : nullptr, c2, shift, flags, bs, flag_parity);

@@ -99,3 +99,37 @@ def test_batched_max_iter(gpu_device):
     assert nb == [3, 3]
     for r in range(2):
         assert np.array_equal(lb[r].cpu().numpy(), O.assign(Xc, cb[r].cpu().numpy()))  # labels match final centres
+
+
+@pytest.mark.parametrize("n,d,k,b", [(4000, 96, 24, 6), (3001, 128, 37, 5), (2500, 64, 8, 20), (6007, 96, 200, 7),
+                                     (2049, 96, 33, 23), (1500, 96, 400, 3)])
+def test_restart_groups_do_not_change_the_result(n, d, k, b, gpu_device, monkeypatch):
+    """mtp_lloyd_batched_f32 with the restarts' centres grouped into shared images (k_assign_mfma_grouped: a workgroup
+    scores its points against R restarts, restart boundaries between accumulator register quads) against one image
+    per restart (k_assign_mfma): every group size -- boundaries at every row offset that a multiple of kp takes in a
+    32-row tile, k not a multiple of 8 (padding rows inside a group), a last group with fewer restarts, more restarts
+    than one group may hold, restarts that pause for a relocation or stop early while their group carries on -- gives
+    the same labels, centres, inertia and iteration counts, bit for bit; and restart 0 those of the single run."""
+    from pccs_accel import kernels as K
+    X = datagen.make_encodings(900 + n, n, d, 10, 2000, 500)
+    Xc = X - X.mean(axis=0)
+    tol = float(O.tolerance(X))
+    C0s = np.stack([Xc[datagen.make_init_indices(60 + r, n, k)] for r in range(b)]).copy()
+    C0s[1, 3] = 50.0             # an unreachable centre: restart 1 pauses for a relocation while its group runs on
+    if b > 4:
+        C0s[4, 0] = -40.0
+    Xd, Cd = dev(Xc, gpu_device), dev(C0s, gpu_device)
+    monkeypatch.setenv("MTP_RESTART_GROUP", "0")
+    ref = K.lloyd_batched(Xd, Cd, tol_abs=tol, check_every=3)
+    l1, i1, c1, n1 = K.lloyd(Xd, dev(C0s[0], gpu_device), tol_abs=tol)
+    assert ref[3][0] == n1 and torch.equal(ref[0][0], l1) and torch.equal(ref[2][0], c1)
+    assert len(set(ref[3])) > 1  # the restarts really stop at different iterations
+    for group in (2, 3, 4, 5, 8, 32):
+        monkeypatch.setenv("MTP_RESTART_GROUP", str(group))
+        for check_every in (1, 4):
+            got = K.lloyd_batched(Xd, Cd, tol_abs=tol, check_every=check_every)
+            assert got[3] == ref[3], (group, got[3], ref[3])
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]) and torch.equal(got[1], ref[1]), group
+    monkeypatch.delenv("MTP_RESTART_GROUP")  # the library's own choice
+    got = K.lloyd_batched(Xd, Cd, tol_abs=tol)
+    assert got[3] == ref[3] and torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
