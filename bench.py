@@ -33,9 +33,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL across processes needs on this pool
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "modular-trajectory-prediction-toolkit_amd"))
@@ -245,6 +247,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-ref-configs", action="store_true", help="skip the reference-sized configs (the five ETH/UCY splits, SDD)")
+    ap.add_argument("--no-convergence", action="store_true",
+                    help="skip the run-to-convergence fit (profiled runs: the per-kernel averages are then those of the timed steps)")
     ap.add_argument("--loop", choices=["library", "python"], default="library",
                     help="library: the K timed iterations are ONE call of mtp_lloyd_sharded_f32 (loop, RCCL all-reduce and "
                          "event timing inside libmtp_accel.so); python: the step-level driver ShardedLloyd.run_fixed "
@@ -385,18 +389,20 @@ def main():
         sl = None
         # SURVEY 8(d) item 4, "run-to-convergence count": the same points from the same C0 with sklearn's tolerance
         # (tol = 1e-4 * mean column variance, _kmeans.py:279-287) to the end, outside the timed region
-        sq = K.col_sqdev(X, torch.zeros(d, dtype=torch.float64, device=device))  # X is centred: deviations from 0
-        if collective:
-            allreduce(sq)
-        tol_abs = float((sq / n).mean().item()) * 1e-4
-        barrier()
-        t0 = time.perf_counter()
-        lab_c, inertia_c, C_c, it_c = pdist.lloyd_sharded_native(comm, X, C0, lo, n, max_iter=300, tol_abs=tol_abs, check_every=8)
-        barrier()
-        convergence = {"n_iter": int(it_c), "total_ms": (time.perf_counter() - t0) * 1e3, "inertia": float(inertia_c),
-                       "tol_abs": tol_abs, "max_iter": 300,
-                       "note": "KMeans(init=C0, n_init=1, tol=1e-4) from the bench's fixed init on all N points, incl. the "
-                               "closing E-step and the inertia; flags checked every 8 iterations"}
+        convergence = lab_c = None
+        if not args.no_convergence:
+            sq = K.col_sqdev(X, torch.zeros(d, dtype=torch.float64, device=device))  # X is centred: deviations from 0
+            if collective:
+                allreduce(sq)
+            tol_abs = float((sq / n).mean().item()) * 1e-4
+            barrier()
+            t0 = time.perf_counter()
+            lab_c, inertia_c, C_c, it_c = pdist.lloyd_sharded_native(comm, X, C0, lo, n, max_iter=300, tol_abs=tol_abs, check_every=8)
+            barrier()
+            convergence = {"n_iter": int(it_c), "total_ms": (time.perf_counter() - t0) * 1e3, "inertia": float(inertia_c),
+                           "tol_abs": tol_abs, "max_iter": 300,
+                           "note": "KMeans(init=C0, n_init=1, tol=1e-4) from the bench's fixed init on all N points, incl. the "
+                                   "closing E-step and the inertia; flags checked every 8 iterations"}
         if comm is not None:
             comm.close()
     else:

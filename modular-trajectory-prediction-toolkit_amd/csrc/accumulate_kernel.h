@@ -11,11 +11,14 @@
 // ACC = double (product) or float (tuning only): the LDS accumulator type.  G = groups of
 // 64/LPR rows whose loads are issued together before their LDS adds.  DO_ADD = false skips the
 // LDS adds (tuning ablation: load-only time).
-template <int LPR, int G, typename ACC, bool DO_ADD>
-__global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X, int64_t n, int d,
+// DT: the feature size as a compile-time constant (0: any d, taken from the argument) -- row addresses and LDS
+// offsets then fold into immediates and shifts.
+template <int LPR, int G, typename ACC, bool DO_ADD, int DT = 0>
+__global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X, int64_t n, int d_rt,
                                                      const int32_t *__restrict__ labels, int k, int kr,
                                                      int64_t rows_per_chunk, double *sums, double *counts,
                                                      const int32_t *state, MtpBatchStride bs) {
+    const int d = DT ? DT : d_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];  // kr*d ACC, then kr ints
     ACC *acc = reinterpret_cast<ACC *>(acc_raw);
     {
@@ -157,11 +160,12 @@ __global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X
 // CU; builds with parts switched off): 37 us with nothing but the label scan and the loop's instructions, +13 us
 // with the row loads, +20 us with the LDS adds (a ds_add_f64 instruction occupies the CU's LDS for 9 clocks
 // whatever its active lanes, tools/lds_atomic_rate), +22 us for the flush.
-template <int LPR, int G>
-__global__ __launch_bounds__(1024) void k_accumulate_all(const float *__restrict__ X, int64_t n, int d,
+template <int LPR, int G, int DT = 0>
+__global__ __launch_bounds__(1024) void k_accumulate_all(const float *__restrict__ X, int64_t n, int d_rt,
                                                          const int32_t *__restrict__ labels, int k,
                                                          int64_t rows_per_chunk, double *sums, double *counts,
                                                          const int32_t *state, MtpBatchStride bs) {
+    const int d = DT ? DT : d_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_raw[];  // k*d doubles, then k ints
     double *acc = reinterpret_cast<double *>(acc_raw);
     // 1-D grid of chunks x restarts.  Workgroup i runs on XCD i % 8: the (chunk, restart) pairs are dealt out chunk-major
