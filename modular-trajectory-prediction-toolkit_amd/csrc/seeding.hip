@@ -105,14 +105,38 @@ extern "C" int64_t mtp_kpp_batched_workspace_bytes(int64_t n, int d, int l, int 
     return (int64_t)kpp_carve(nullptr, n, d, l, batch).bytes;
 }
 
+// ||row||^2 of the upcast row in the double summation order of NumPy's einsum("ij,ij->i") -- what sklearn's
+// _euclidean_distances_upcast runs for XX and YY (row_norms(X.astype(float64), squared=True),
+// metrics/pairwise.py:391-442): x86-64 baseline SIMD, two lane accumulators (element e -> lane e % 2), product
+// rounded then added, full blocks of 8 elements consumed vector 3, 2, 1, 0, the remaining vectors in order,
+// l0 + l1 (established against np.einsum itself, tests/test_oracle_golden.py; restated in oracle.c).
+// The order only shows where the distance cancels: a candidate that coincides with a point (duplicate rows, fixture
+// G16) must get (-2 x.y + |x|^2) + |y|^2 with |x|^2 and |y|^2 the SAME bits, as sklearn does.
+// `lane2` = 0 or 1: the accumulator this call walks; the caller adds the two.
+__device__ inline double kpp_sqnorm_einsum_f64_lane(const float *a, int d, int lane2) {
+    double l = 0.0;
+    int e = 0;
+    for (; e + 8 <= d; e += 8)
+        for (int v = 3; v >= 0; --v) {
+            const double x = (double)a[e + 2 * v + lane2];
+            l = l + x * x;
+        }
+    for (; e < d; e += 2)
+        if (e + lane2 < d) {
+            const double x = (double)a[e + lane2];
+            l = l + x * x;
+        }
+    return l;
+}
+__device__ inline double kpp_sqnorm_einsum_f64(const float *a, int d) {
+    return kpp_sqnorm_einsum_f64_lane(a, d, 0) + kpp_sqnorm_einsum_f64_lane(a, d, 1);
+}
+
 // |y|^2 per row in double
 __global__ __launch_bounds__(256) void k_kpp_rownorm(const float *__restrict__ X, int64_t n, int d, double *yy) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float *x = X + i * d;
-    double s = 0.0;
-    for (int k = 0; k < d; ++k) s = fma((double)x[k], (double)x[k], s);
-    yy[i] = s;
+    yy[i] = kpp_sqnorm_einsum_f64(X + i * d, d);
 }
 
 // Distances from n_cand (<= LT) candidate rows (double, in cand_x) to every point; min with the
@@ -1067,13 +1091,10 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
         if (lane == 0) cand[l] = id;
         // gather the candidate row in double and its squared norm
         const float *x = X + id * d;
-        double xx = 0.0;
-        for (int k = lane; k < d; k += 64) {
-            const double v = (double)x[k];
-            cand_x[(size_t)k * ltile + l] = v;
-            xx += v * v;
-        }
-        for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
+        for (int k = lane; k < d; k += 64) cand_x[(size_t)k * ltile + l] = (double)x[k];
+        // the two accumulators of the einsum order on lanes 0 and 1 (the same bits as yy[id])
+        double xx = lane < 2 ? kpp_sqnorm_einsum_f64_lane(x, d, lane) : 0.0;
+        xx += __shfl_xor(xx, 1);
         if (lane == 0) cand_xx[l] = xx;
     }
 }
@@ -1087,13 +1108,9 @@ __global__ __launch_bounds__(64) void k_kpp_first(const float *__restrict__ X, i
     cand_x = kpp_at(cand_x, bstride, blockIdx.x);
     cand_xx = kpp_at(cand_xx, bstride, blockIdx.x);
     const float *x = X + center_id * d;
-    double xx = 0.0;
-    for (int k = lane; k < d; k += 64) {
-        const double v = (double)x[k];
-        cand_x[(size_t)k * ltile] = v;
-        xx += v * v;
-    }
-    for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
+    for (int k = lane; k < d; k += 64) cand_x[(size_t)k * ltile] = (double)x[k];
+    double xx = lane < 2 ? kpp_sqnorm_einsum_f64_lane(x, d, lane) : 0.0;
+    xx += __shfl_xor(xx, 1);
     if (lane == 0) {
         cand_xx[0] = xx;
         cand[0] = center_id;
@@ -1213,20 +1230,16 @@ extern "C" int mtp_kmeans_plusplus_batched_f32(const float *X, int64_t n, int d,
 // ------------------------------------------------------------------------------------------
 
 // candidate rows (float, [batch][n_cand][d]) -> the kernels' operand form: double, feature-major
-// [d][8] per restart, and |x|^2 summed exactly as k_kpp_select / k_kpp_first do (lane-strided
-// partial sums, xor tree), so a one-rank run carries the fused path's bits.
+// [d][8] per restart, and |x|^2 summed exactly as k_kpp_select / k_kpp_first do (NumPy's einsum order,
+// kpp_sqnorm_einsum_f64), so a one-rank run carries the fused path's bits.
 __global__ __launch_bounds__(64) void k_kpp_stage_cands(const float *__restrict__ cand, int d, int n_cand,
                                                         double *cand_x, double *cand_xx) {
     const int b = blockIdx.y, l = blockIdx.x, lane = threadIdx.x;
     const float *x = cand + ((size_t)b * n_cand + l) * d;
     double *cx = cand_x + (size_t)b * d * 8;
-    double xx = 0.0;
-    for (int k = lane; k < d; k += 64) {
-        const double v = (double)x[k];
-        cx[(size_t)k * 8 + l] = v;
-        xx += v * v;
-    }
-    for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
+    for (int k = lane; k < d; k += 64) cx[(size_t)k * 8 + l] = (double)x[k];
+    double xx = lane < 2 ? kpp_sqnorm_einsum_f64_lane(x, d, lane) : 0.0;
+    xx += __shfl_xor(xx, 1);
     if (lane == 0) cand_xx[(size_t)b * 8 + l] = xx;
 }
 

@@ -123,6 +123,24 @@ void orc_row_sqnorm_f32(const float *A, int64_t n, int d, float *out) {
     }
 }
 
+/* The same for a float row upcast to double (row_norms(X.astype(float64), squared=True) inside sklearn's
+ * _euclidean_distances_upcast, metrics/pairwise.py:391-442 -- the |x|^2 and |y|^2 of the k-means++ distances):
+ * two lane accumulators (element e -> lane e % 2), full blocks of 8 elements consumed vector 3,2,1,0, the remaining
+ * vectors in order, l0 + l1.  tests/test_oracle_golden.py pins this against np.einsum itself. */
+void orc_row_sqnorm_upcast_f64(const float *A, int64_t n, int d, double *out) {
+    for (int64_t i = 0; i < n; ++i) {
+        const float *a = A + i * d;
+        double l[2] = {0.0, 0.0};
+        int e = 0;
+        for (; e + 8 <= d; e += 8)
+            for (int v = 3; v >= 0; --v)
+                for (int q = 0; q < 2; ++q) l[q] = l[q] + (double)a[e + 2 * v + q] * (double)a[e + 2 * v + q];
+        for (; e < d; e += 2)
+            for (int q = 0; q < 2 && e + q < d; ++q) l[q] = l[q] + (double)a[e + q] * (double)a[e + q];
+        out[i] = l[0] + l[1];
+    }
+}
+
 /* ------------------------------------------------------------------------------------
  * M-step sums, single-thread sample order in float (what sklearn does with one thread;
  * with several threads sklearn's own result depends on the lock order, :143-152).

@@ -478,6 +478,42 @@ def gen_g15(utility, only=None):
              labels=labels.astype(np.uint8 if K <= 256 else np.uint16), sizes=sizes)
 
 
+def gen_g16():
+    """Fewer distinct points than clusters (300 rows drawn from 5 distinct ones, K = 8): the degenerate corner of
+    sklearn's Lloyd loop -- clusters stay empty, the relocation finds (nearly) zero distances, `_average_centers`
+    copies the heaviest cluster's centre (_k_means_common.pyx:291-295), KMeans warns that fewer distinct clusters
+    than asked were found -- and of k-means++ (all potentials zero once every distinct point is a centre: the
+    remaining draws all land on index 0).  Recorded on ONE thread (threadpool_limits(1)): in this corner sklearn's
+    result depends on the rounding of its float32 sums, so its 8-thread and 1-thread runs differ in the empty
+    clusters' centres; the one-thread run is the deterministic one and what sums="sklearn_1t" must reproduce."""
+    from sklearn.cluster import KMeans
+    from sklearn.cluster._kmeans import _kmeans_plusplus
+    from sklearn.utils.extmath import row_norms
+    from threadpoolctl import threadpool_limits
+    rs = np.random.RandomState(3)
+    base = rs.randn(5, 96).astype(np.float32)
+    X = base[rs.randint(0, 5, size=300)].copy()
+    K = 8
+    C0 = X[:K].copy()
+    out = dict(X=X, C0=C0, K=K)
+    with threadpool_limits(limits=1), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        km = KMeans(n_clusters=K, init=C0, n_init=1).fit(X)
+        assert any("distinct clusters" in str(m.message) for m in w)
+        out.update(labels=km.labels_.astype(np.int32), centers=km.cluster_centers_, n_iter=km.n_iter_, inertia=np.float64(km.inertia_))
+        Xc = X - X.mean(axis=0)
+        idx = []
+        for seed in (0, 1, 2):
+            _, i = _kmeans_plusplus(Xc, K, row_norms(Xc, squared=True), np.ones(300, dtype=np.float32), np.random.RandomState(seed))
+            idx.append(i)
+        out["kpp_indices"] = np.stack(idx).astype(np.int64)
+        np.random.seed(5)
+        km2 = KMeans(n_clusters=K, n_init=3).fit(X)
+        out.update(fit_labels=km2.labels_.astype(np.int32), fit_centers=km2.cluster_centers_, fit_n_iter=km2.n_iter_,
+                   fit_inertia=np.float64(km2.inertia_))
+    save("g16_fewer_distinct_points_than_clusters", **out)
+
+
 if __name__ == "__main__":
     warnings.simplefilter("error")  # a ConvergenceWarning here means a bad fixture
     utility, metrics = _import_ref("PCCSNet")
@@ -486,7 +522,7 @@ if __name__ == "__main__":
     g15_only = [a for a in sys.argv[1:] if a.startswith("g15_")]
     jobs = dict(g1=lambda: gen_g1(utility), g2=lambda: gen_g2(utility), g45=gen_g4_g5,
                 g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, g13=gen_g13,
-                g14=lambda: gen_g14(utility, g14_only or None), g15=lambda: gen_g15(utility, g15_only or None))
+                g14=lambda: gen_g14(utility, g14_only or None), g15=lambda: gen_g15(utility, g15_only or None), g16=gen_g16)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

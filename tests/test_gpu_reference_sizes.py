@@ -274,3 +274,50 @@ def test_one_thread_mode_with_relocation_and_generic_d(gpu_device):
         assert np.array_equal(labels.cpu().numpy(), ol), seed
         assert np.array_equal(centers.cpu().numpy().view(np.uint32), oc.view(np.uint32)), seed
         assert inertia == oi, (seed, inertia, oi)
+
+
+def test_degenerate_duplicates_match_sklearn_one_thread(gpu_device):
+    """Fixture G16 (sklearn on one thread; 300 rows drawn from 5 distinct ones, K = 8): the degenerate corner of the
+    loop -- clusters that stay empty, a relocation over (nearly) zero distances, the heaviest cluster's centre copied
+    into the empty ones (_k_means_common.pyx:291-295), sklearn's "fewer distinct clusters" warning, k-means++ once
+    every distinct point is a centre -- through the product in sums="sklearn_1t" mode: labels, centres bit for bit (the
+    empty clusters' included), n_iter, inertia from the given init; the seeds while distinct points remain; the
+    partition of the whole seeded fit."""
+    import warnings
+    from pccs_accel import clustering, seeding
+    g = load_golden("g16_fewer_distinct_points_than_clusters")
+    X, C0, K = g["X"], g["C0"], int(g["K"])
+    Xd = torch.from_numpy(X).to(gpu_device)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        fit = clustering.kmeans_fit(Xd, K, init=C0, n_init=1, sums="sklearn_1t")
+    assert any(issubclass(m.category, clustering.ConvergenceWarning) for m in w)
+    assert fit["n_iter"] == int(g["n_iter"])
+    assert np.array_equal(fit["labels"].cpu().numpy(), g["labels"])
+    assert np.array_equal(fit["centers"].cpu().numpy().view(np.uint32), g["centers"].view(np.uint32))
+    assert fit["inertia"] == float(g["inertia"])
+    Xc = Xd - fit["x_mean"]
+    # k-means++: sklearn's seeds while there are distinct points left to pick (the first 5 centres).  After that
+    # every closest distance is (-2 x.y + |x|^2) + |y|^2 of coincident rows: cancellation noise of +-1e-16 |x|^2 whose
+    # sign -- 0 after the clamp, or a tiny positive float -- depends on the accumulation order of the dgemm kernel
+    # OpenBLAS picks for the matrix shape (a small-matrix kernel here, not the one of the reference's sizes).  Those
+    # draws are PARITY UNPINNED; they must still be valid rows, and the partition the fit finds is the same.
+    for s, seed in enumerate((0, 1, 2)):
+        _, idx = seeding.kmeans_plusplus(Xc.contiguous(), K, np.random.RandomState(seed))
+        idx = idx.cpu().numpy()
+        assert np.array_equal(idx[:5], g["kpp_indices"][s][:5]), seed
+        assert len({X[i].tobytes() for i in idx[:5]}) == 5 and ((idx >= 0) & (idx < X.shape[0])).all()
+    np.random.seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fit3 = clustering.kmeans_fit(Xd, K, n_init=3, sums="sklearn_1t")
+    l3 = fit3["labels"].cpu().numpy()
+    assert O.is_same_clustering(l3, g["fit_labels"], K) and O.is_same_clustering(g["fit_labels"], l3, K)
+    assert fit3["inertia"] < 1e-6 and float(g["fit_inertia"]) < 1e-6   # every point sits on its centre
+    # the default mode (double sums): the same labels; the populated clusters' centres to rounding
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fit64 = clustering.kmeans_fit(Xd, K, init=C0, n_init=1)
+    assert np.array_equal(fit64["labels"].cpu().numpy(), g["labels"])
+    used = np.unique(g["labels"])
+    assert np.allclose(fit64["centers"].cpu().numpy()[used], g["centers"][used], rtol=1e-5, atol=2e-6)

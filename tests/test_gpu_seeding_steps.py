@@ -27,6 +27,8 @@ def test_candidate_dists_match_oracle(n, d, b, l, gpu_device):
     Xd = dev(X, gpu_device)
     yy = ops.row_sqnorm(Xd)
     assert np.allclose(yy.cpu().numpy()[:n], (X.astype(np.float64) ** 2).sum(axis=1), rtol=1e-14)
+    # ... and in the double summation order of NumPy's einsum (sklearn's row_norms on the upcast rows), bit for bit
+    assert np.array_equal(yy.cpu().numpy()[:n].view(np.uint64), O.row_sqnorm_upcast_f64(X).view(np.uint64))
     for prev in (None, closest):
         rows, pot = ops.candidate_dists(Xd, yy, dev(cand, gpu_device), None if prev is None else dev(prev, gpu_device))
         rows, pot = rows.cpu().numpy(), pot.cpu().numpy()
