@@ -514,6 +514,26 @@ def gen_g16():
     save("g16_fewer_distinct_points_than_clusters", **out)
 
 
+def gen_g17():
+    """The ends of the cluster-count range on one thread: K = 1, 2, N - 1, N for N = 200 rows (d = 96), the whole seeded
+    ``KMeans(K, n_init=3).fit`` -- k-means++ with L = 2 + int(ln K) local trials from 2 to 7, a single cluster, a run
+    where every point is a centre (inertia 0, strict convergence in the first iteration)."""
+    from sklearn.cluster import KMeans
+    from threadpoolctl import threadpool_limits
+    X = datagen.make_encodings(5, 200, 96, 6, 2000, 500)
+    out = dict(X=X, Ks=np.array([1, 2, 199, 200]), np_seed=4)
+    with threadpool_limits(limits=1), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for K in (1, 2, 199, 200):
+            np.random.seed(4)
+            km = KMeans(n_clusters=K, n_init=3).fit(X)
+            out[f"labels_{K}"] = km.labels_.astype(np.int32)
+            out[f"centers_{K}"] = km.cluster_centers_
+            out[f"n_iter_{K}"] = km.n_iter_
+            out[f"inertia_{K}"] = np.float64(km.inertia_)
+    save("g17_extreme_cluster_counts", **out)
+
+
 if __name__ == "__main__":
     warnings.simplefilter("error")  # a ConvergenceWarning here means a bad fixture
     utility, metrics = _import_ref("PCCSNet")
@@ -522,7 +542,7 @@ if __name__ == "__main__":
     g15_only = [a for a in sys.argv[1:] if a.startswith("g15_")]
     jobs = dict(g1=lambda: gen_g1(utility), g2=lambda: gen_g2(utility), g45=gen_g4_g5,
                 g6=lambda: gen_g6(metrics), g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, g13=gen_g13,
-                g14=lambda: gen_g14(utility, g14_only or None), g15=lambda: gen_g15(utility, g15_only or None), g16=gen_g16)
+                g14=lambda: gen_g14(utility, g14_only or None), g15=lambda: gen_g15(utility, g15_only or None), g16=gen_g16, g17=gen_g17)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

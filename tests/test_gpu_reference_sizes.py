@@ -321,3 +321,19 @@ def test_degenerate_duplicates_match_sklearn_one_thread(gpu_device):
     assert np.array_equal(fit64["labels"].cpu().numpy(), g["labels"])
     used = np.unique(g["labels"])
     assert np.allclose(fit64["centers"].cpu().numpy()[used], g["centers"][used], rtol=1e-5, atol=2e-6)
+
+
+def test_extreme_cluster_counts_match_sklearn_one_thread(gpu_device):
+    """Fixture G17 (sklearn on one thread): K = 1, 2, N - 1 and N clusters for N = 200 points, whole seeded fits with
+    n_init = 3 -- 2 to 7 local trials in k-means++, a single cluster, every point its own centre -- in
+    sums="sklearn_1t" mode: labels and centres bit for bit, n_iter, inertia."""
+    from pccs_accel import clustering
+    g = load_golden("g17_extreme_cluster_counts")
+    Xd = torch.from_numpy(g["X"]).to(gpu_device)
+    for K in g["Ks"].tolist():
+        np.random.seed(int(g["np_seed"]))
+        fit = clustering.kmeans_fit(Xd, K, n_init=3, sums="sklearn_1t")
+        assert fit["n_iter"] == int(g[f"n_iter_{K}"]), K
+        assert np.array_equal(fit["labels"].cpu().numpy(), g[f"labels_{K}"]), K
+        assert np.array_equal(fit["centers"].cpu().numpy().view(np.uint32), g[f"centers_{K}"].view(np.uint32)), K
+        assert fit["inertia"] == float(g[f"inertia_{K}"]), K
