@@ -128,9 +128,21 @@ __device__ inline double kpp_sqnorm_einsum_f64_lane(const float *a, int d, int l
         }
     return l;
 }
+// the same chain over squares that are already formed (sq[e] = double(a[e]) * double(a[e]), rounded once, as above)
+__device__ inline double kpp_sqnorm_einsum_f64_lane_sq(const double *sq, int d, int lane2) {
+    double l = 0.0;
+    int e = 0;
+    for (; e + 8 <= d; e += 8)
+        for (int v = 3; v >= 0; --v) l = l + sq[e + 2 * v + lane2];
+    for (; e < d; e += 2)
+        if (e + lane2 < d) l = l + sq[e + lane2];
+    return l;
+}
 __device__ inline double kpp_sqnorm_einsum_f64(const float *a, int d) {
     return kpp_sqnorm_einsum_f64_lane(a, d, 0) + kpp_sqnorm_einsum_f64_lane(a, d, 1);
 }
+
+static constexpr int KPP_NORM_LDS = 256;  // rows up to this many features are staged in LDS for the norm chains
 
 // |y|^2 per row in double
 __global__ __launch_bounds__(256) void k_kpp_rownorm(const float *__restrict__ X, int64_t n, int d, double *yy) {
@@ -948,7 +960,8 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
                                                      size_t bstride, size_t u_stride /* doubles */,
                                                      size_t index_stride /* int64s */, int ltile,
                                                      const float *pot_part /* NULL: double sums */, int64_t pot_nb,
-                                                     int pot_tail, double *pot64, double pot_eps) {
+                                                     int pot_tail, double *pot64, double pot_eps,
+                                                     const double *__restrict__ yy) {
     {
         const int b = blockIdx.x;
         if (pot_part != nullptr) pot_part = kpp_at(pot_part, bstride, b);
@@ -1092,16 +1105,16 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
         // gather the candidate row in double and its squared norm
         const float *x = X + id * d;
         for (int k = lane; k < d; k += 64) cand_x[(size_t)k * ltile + l] = (double)x[k];
-        // the two accumulators of the einsum order on lanes 0 and 1 (the same bits as yy[id])
-        double xx = lane < 2 ? kpp_sqnorm_einsum_f64_lane(x, d, lane) : 0.0;
-        xx += __shfl_xor(xx, 1);
-        if (lane == 0) cand_xx[l] = xx;
+        // |x|^2: the candidate is row `id` of X, whose norm k_kpp_rownorm has already formed in NumPy's einsum order --
+        // the very bits the distance kernel adds as |y|^2 for that point, as in sklearn
+        if (lane == 0) cand_xx[l] = yy[id];
     }
 }
 
 __global__ __launch_bounds__(64) void k_kpp_first(const float *__restrict__ X, int d, int64_t center_id,
                                                   const int64_t *center_ids, int64_t *cand, double *cand_x,
-                                                  double *cand_xx, size_t bstride, int ltile) {
+                                                  double *cand_xx, size_t bstride, int ltile,
+                                                  const double *__restrict__ yy) {
     const int lane = threadIdx.x;
     if (center_ids != nullptr) center_id = center_ids[blockIdx.x];
     cand = kpp_at(cand, bstride, blockIdx.x);
@@ -1109,10 +1122,8 @@ __global__ __launch_bounds__(64) void k_kpp_first(const float *__restrict__ X, i
     cand_xx = kpp_at(cand_xx, bstride, blockIdx.x);
     const float *x = X + center_id * d;
     for (int k = lane; k < d; k += 64) cand_x[(size_t)k * ltile] = (double)x[k];
-    double xx = lane < 2 ? kpp_sqnorm_einsum_f64_lane(x, d, lane) : 0.0;
-    xx += __shfl_xor(xx, 1);
     if (lane == 0) {
-        cand_xx[0] = xx;
+        cand_xx[0] = yy[center_id];  // the row's norm in NumPy's einsum order (k_kpp_rownorm)
         cand[0] = center_id;
     }
 }
@@ -1153,7 +1164,7 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
     MTP_LAUNCH_CHECK();
     const int ltile = kpp_ltile(l);
     hipLaunchKernelGGL(k_kpp_first, dim3(batch), dim3(64), 0, s, X, d, center_id, center_ids_dev, w.cand, w.cand_x,
-                       w.cand_xx, w.stride, ltile);
+                       w.cand_xx, w.stride, ltile, w.yy);
     MTP_LAUNCH_CHECK();
     MTP_HIP(hipMemset2DAsync(w.pot64, w.stride, 0, KPP_MAX_L * 8, batch, s));
     // closest distances to the first centre: one "candidate", no previous row
@@ -1188,12 +1199,12 @@ static int kpp_run(const float *X, int64_t n, int d, int k, int l, int batch, in
             hipLaunchKernelGGL(k_kpp_select<KPP_TP / 64>, dim3(batch), dim3(1024), 0, s, X, n, d, n_prev, n_new,
                                c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
                                w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1), w.stride, u_stride, (size_t)k,
-                               ltile, pot_part, pot_nb, pot_tail, w.pot64, pot_eps);
+                               ltile, pot_part, pot_nb, pot_tail, w.pot64, pot_eps, w.yy);
         else
             hipLaunchKernelGGL(k_kpp_select<KPP_PB / 64>, dim3(batch), dim3(1024), 0, s, X, n, d, n_prev, n_new,
                                c < k ? u + (size_t)(c - 1) * l : nullptr, rows_cur, bsum_cur, nblk, w.prefix, w.cand,
                                w.cand_x, w.cand_xx, w.state, w.pot, indices_out + (c - 1), w.stride, u_stride, (size_t)k,
-                               ltile, pot_part, pot_nb, pot_tail, w.pot64, pot_eps);
+                               ltile, pot_part, pot_nb, pot_tail, w.pot64, pot_eps, w.yy);
         MTP_LAUNCH_CHECK();
         if (c == k) break;
         float *rows_nxt = w.rows + (size_t)(cur ^ 1) * l * n;
@@ -1237,8 +1248,16 @@ __global__ __launch_bounds__(64) void k_kpp_stage_cands(const float *__restrict_
     const int b = blockIdx.y, l = blockIdx.x, lane = threadIdx.x;
     const float *x = cand + ((size_t)b * n_cand + l) * d;
     double *cx = cand_x + (size_t)b * d * 8;
-    for (int k = lane; k < d; k += 64) cx[(size_t)k * 8 + l] = (double)x[k];
-    double xx = lane < 2 ? kpp_sqnorm_einsum_f64_lane(x, d, lane) : 0.0;
+    __shared__ double s_sq[KPP_NORM_LDS];
+    const bool via_lds = d <= KPP_NORM_LDS;
+    for (int k = lane; k < d; k += 64) {
+        const double v = (double)x[k];
+        cx[(size_t)k * 8 + l] = v;
+        if (via_lds) s_sq[k] = v * v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double xx = 0.0;
+    if (lane < 2) xx = via_lds ? kpp_sqnorm_einsum_f64_lane_sq(s_sq, d, lane) : kpp_sqnorm_einsum_f64_lane(x, d, lane);
     xx += __shfl_xor(xx, 1);
     if (lane == 0) cand_xx[(size_t)b * 8 + l] = xx;
 }
