@@ -142,6 +142,8 @@ __device__ inline double kpp_sqnorm_einsum_f64(const float *a, int d) {
     return kpp_sqnorm_einsum_f64_lane(a, d, 0) + kpp_sqnorm_einsum_f64_lane(a, d, 1);
 }
 
+static constexpr int KPP_PART_LDS = 2048;    // float32 block sums of the candidate rows held in LDS by k_kpp_select
+static constexpr int KPP_PREFIX_LDS = 1024;  // block-sum prefixes held in LDS (one chunk of the scan) instead of global
 static constexpr int KPP_NORM_LDS = 256;  // rows up to this many features are staged in LDS for the norm chains
 
 // |y|^2 per row in double
@@ -980,6 +982,8 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
     __shared__ double red[16];
     __shared__ double red_l[KPP_MAX_L][16];
     __shared__ float pots[KPP_MAX_L];
+    __shared__ float s_part[KPP_PART_LDS];
+    __shared__ double s_prefix[KPP_PREFIX_LDS];
     __shared__ int s_sel;
     __shared__ double s_rand[KPP_MAX_L];
     __shared__ int s_blk[KPP_MAX_L];
@@ -1001,19 +1005,30 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
             for (int w = 0; w < 16; ++w) t += red_l[tid][w];
             pots[tid] = (float)t;
         }
-    } else if (tid < n_prev) {
+    } else {
+        // the block sums come in through LDS, fetched by all threads at once: walked straight from global memory
+        // the chain below paid an L1 round trip per block (2 us of this kernel's 9.5 at 18 blocks)
+        const bool part_lds = (int64_t)n_prev * pot_nb <= KPP_PART_LDS;
+        if (part_lds)
+            for (int e = tid; e < n_prev * (int)pot_nb; e += 1024) s_part[e] = pot_part[e];
+        __syncthreads();
+        if (tid < n_prev) {
         // OpenBLAS order (see k_kpp_pot_blocks): y += block sum, block by block, then the n & 3 trailing points;
         // rows that cannot hold the smallest potential were not summed and are out of the argmin
         float y = __builtin_inff();
         if (n_prev == 1 || kpp_contender(pot64, n_prev, tid, pot_eps)) {
             y = 0.f;
-            for (int64_t b = 0; b < pot_nb; ++b) y = y + pot_part[(size_t)tid * pot_nb + b];
+            if (part_lds)
+                for (int b = 0; b < (int)pot_nb; ++b) y = y + s_part[tid * (int)pot_nb + b];
+            else
+                for (int64_t b = 0; b < pot_nb; ++b) y = y + pot_part[(size_t)tid * pot_nb + b];
             const float *tail = rows_cur + (size_t)tid * n + (n - pot_tail);
             if (pot_tail == 3) y = y + ((tail[0] + tail[1]) + tail[2]);
             else if (pot_tail == 2) y = y + (tail[0] + tail[1]);
             else if (pot_tail == 1) y = y + tail[0];
         }
         pots[tid] = y;
+        }
     }
     __syncthreads();
     if (tid < KPP_MAX_L) pot64[tid] = 0.0;  // the next distance kernel adds its rows' block sums here
@@ -1053,7 +1068,10 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
         for (int w = 0; w < wave; ++w) woff += red[w];
         const double carry = s_carry;
         v += woff + carry;
-        if (b < nblk) prefix[b] = v;
+        if (b < nblk) {
+            if (nblk <= KPP_PREFIX_LDS) s_prefix[b] = v;  // read back below: no trip through global memory
+            else prefix[b] = v;
+        }
         for (int l = 0; l < n_new; ++l) {  // one LDS atomic per wave and candidate
             const unsigned long long below = __ballot(b < nblk && v < s_rand[l]);
             if (lane == 0 && below) atomicAdd(&s_blk[l], (int)__popcll(below));
@@ -1068,7 +1086,7 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
         const int blk = s_blk[l];
         int64_t id = n - 1;
         if (blk < nblk) {
-            const double start = blk > 0 ? prefix[blk - 1] : 0.0;
+            const double start = blk > 0 ? (nblk <= KPP_PREFIX_LDS ? s_prefix[blk - 1] : prefix[blk - 1]) : 0.0;
             constexpr int PB = 64 * KPP_Q;  // points per block sum
             const int64_t p0 = (int64_t)blk * PB + lane * KPP_Q;
             double loc[KPP_Q];
