@@ -435,6 +435,41 @@ struct KppStrides {
 };
 __host__ inline KppStrides kpp_uniform_strides(size_t s) { return KppStrides{s, s, s, s, s, s, s}; }
 
+// 16-lane sums of doubles on the vector pipe (DPP row operations on the two halves of the double) in the order of the
+// xor butterfly `s += shfl_xor(s, 1); s += shfl_xor(s, 2); s += shfl_xor(s, 4); s += shfl_xor(s, 8)`: after the
+// steps 1 and 2 the four lanes of a quad hold the same bits (a + b == b + a), so "the lane 4 (8) away" of steps 3
+// and 4 can be any lane of the other quad (half row) -- row_half_mirror and row_mirror.  ds_bpermute took a trip
+// through the LDS per step and half of the double; eight sums per wave made that the longest chain of the epilogue.
+template <int CTRL>
+__device__ __forceinline__ double kpp_dpp_f64(double v) {
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int NS>
+__device__ __forceinline__ void kpp_row16_sums(double (&s)[NS]) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] += kpp_dpp_f64<0xB1>(s[i]);   // quad_perm [1, 0, 3, 2]
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] += kpp_dpp_f64<0x4E>(s[i]);   // quad_perm [2, 3, 0, 1]
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] += kpp_dpp_f64<0x141>(s[i]);  // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] += kpp_dpp_f64<0x140>(s[i]);  // row_mirror
+}
+
+// A workgroup lives for ~30 us at any load, and what it lives through is a sequence of DEPENDENT phases, so the
+// kernel is written to keep that sequence short (round 3; the arithmetic is untouched):
+//  * the first two chunks of points and candidates are requested before anything else -- the indices of the
+//    closest-so-far rows (scalar loads) and |y|^2 follow, all issued without waiting for one another (they used to
+//    be four conditional scalar loads, each waited for, in front of the first point load);
+//  * the candidates' |x|^2 go to LDS with the first chunk (they were global loads inside the epilogue, one trip per
+//    restart of the column);
+//  * the closest-so-far values are requested in the LAST chunk pair, when the chunk registers are free, and have
+//    landed when the MFMAs are through (they were loaded restart by restart in the epilogue, each load behind the
+//    stores of the restart before, since the rows may alias);
+//  * the epilogue computes all values, then reduces the column's eight sums side by side with DPP.
 template <int WP, int QB, int MINB = 2>
 __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__restrict__ X, int64_t n, int d, int n_cand,
                                                           const double *__restrict__ cand_x0,
@@ -452,6 +487,9 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
     __shared__ __attribute__((aligned(16))) double ys_[2][KPP_MK][YS];
     __shared__ __attribute__((aligned(16))) double cs_[2][KPP_MK][CS];
     __shared__ double part[WP][NC];
+    // |x|^2 of the column's candidates (0 where there is none), in the order the epilogue's lanes read them: lane
+    // group g holds the candidates 4 e + g of its wave's QB blocks x 2 restarts -- QB * 4 consecutive doubles
+    __shared__ __attribute__((aligned(16))) double cxx_s[4][NC / 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: restart indices / pointers stay scalar
     const int j = lane & 15, g = lane >> 4;
@@ -469,32 +507,11 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
     const int64_t row0 = bx * KPP_TP;
     const int b0 = by * RB;
 
-    f64x4 acc[PB][QB];
-#pragma unroll
-    for (int p = 0; p < PB; ++p)
-#pragma unroll
-        for (int q = 0; q < QB; ++q) acc[p][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
-
     constexpr int XPIECES = KPP_TP * (KPP_MK / 4);               // float4 pieces of X per chunk (256)
     static_assert(XPIECES == 256, "one float4 of X per thread and chunk");
     constexpr int CPIECES = RB * KPP_MK * 4;                     // double2 pieces of the candidate tiles
     constexpr int CV = (CPIECES + 255) / 256;
-    // The first hop of the epilogue's dependent loads (which of the previous rows is the closest-so-far
-    // one: wave-uniform) and |y|^2 are requested now, behind the MFMA loop.
-    double yyv[PB];
-#pragma unroll
-    for (int p = 0; p < PB; ++p) {
-        const int64_t i = row0 + (wp * PB + p) * 16 + j;
-        yyv[p] = yy[i < n ? i : n - 1];
-    }
-    int selv[QB][2];
-#pragma unroll
-    for (int q = 0; q < QB; ++q)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int b = b0 + (wc * QB + q) * 2 + h;
-            selv[q][h] = (b < batch && has_prev) ? *kpp_at(sel_prev0, st.sel, b) : 0;
-        }
+    static_assert(NC <= 256, "one thread per candidate column");
 
     // Global loads run TWO chunks ahead of the MFMAs (two register sets, loop unrolled by two): one
     // chunk's MFMAs are shorter than a trip to L2 / HBM.
@@ -520,6 +537,38 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
                 rg.c[i] = *reinterpret_cast<const double2 *>(kpp_at(cand_x0, st.cand_x, b) + (size_t)kc * 8 + 2 * w2);
         }
     };
+    // d is a multiple of 16 (kpp_tile_path): an even number of chunks
+    fetch(0, ra);
+    fetch(KPP_MK, rb);
+
+    // behind them, none waiting for another: |x|^2 of this thread's candidate column and which of the previous rows
+    // is the closest-so-far one (wave-uniform: scalar loads)
+    double cxv = 0.0;
+    if (tid < NC) {
+        const int b = b0 + (tid >> 3), l = tid & 7;
+        if (b < batch && l < n_cand) cxv = kpp_at(cand_xx0, st.cand_xx, b)[l];
+    }
+    int selv[QB][2];
+#pragma unroll
+    for (int q = 0; q < QB; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) selv[q][h] = 0;
+    if (has_prev) {  // uniform; the restart index is clamped so that the four loads are unconditional and go out together
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int b = b0 + (wc * QB + q) * 2 + h;
+                selv[q][h] = *kpp_at(sel_prev0, st.sel, b < batch ? b : batch - 1);
+            }
+    }
+
+    f64x4 acc[PB][QB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc[p][q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
     auto deposit = [&](int buf, const Regs &rg) {
         {
             const int r = tid / (KPP_MK / 4), q4 = tid % (KPP_MK / 4);
@@ -551,21 +600,51 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
         }
     };
 
-    // d is a multiple of 16 (kpp_tile_path): an even number of chunks
-    fetch(0, ra);
-    fetch(KPP_MK, rb);
-    for (int kc = 0; kc < d; kc += 2 * KPP_MK) {
+    if (tid < NC) cxx_s[tid & 3][(tid >> 4) * 4 + ((tid >> 3) & 1) * 2 + ((tid >> 2) & 1)] = cxv;  // published by the first barrier below
+    // all chunk pairs but the last: the loads of the pair after the next are issued as the registers come free
+    int kc = 0;
+    for (; kc + 2 * KPP_MK < d; kc += 2 * KPP_MK) {
         deposit(0, ra);
         __syncthreads();  // chunk visible; every wave is past the MFMAs that read this buffer two chunks ago
-        if (kc + 2 * KPP_MK < d) fetch(kc + 2 * KPP_MK, ra);
+        fetch(kc + 2 * KPP_MK, ra);
         compute(0);
         deposit(1, rb);
         __syncthreads();
-        if (kc + 3 * KPP_MK < d) fetch(kc + 3 * KPP_MK, rb);
+        fetch(kc + 3 * KPP_MK, rb);
         compute(1);
     }
+    // the last pair: instead of chunks, the closest-so-far values and |y|^2 of this lane's points are requested
+    deposit(0, ra);
+    __syncthreads();
+    float oldv[QB][2][PB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = b0 + (wc * QB + q) * 2 + h;
+            const float *prev = kpp_at(rows_prev0, st.rows_prev, b < batch ? b : batch - 1) + (size_t)selv[q][h] * n;
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const int64_t i = row0 + (wp * PB + p) * 16 + j;
+                oldv[q][h][p] = __builtin_inff();
+                if (has_prev) oldv[q][h][p] = prev[i < n ? i : n - 1];
+            }
+        }
+    double yyv[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int64_t i = row0 + (wp * PB + p) * 16 + j;
+        yyv[p] = yy[i < n ? i : n - 1];
+    }
+    compute(0);
+    deposit(1, rb);
+    __syncthreads();
+    compute(1);
 
     // epilogue: distance, clamp, min with the closest-so-far row, store, block sums
+    double sums[QB * 4], cxxv[QB * 4];
+#pragma unroll
+    for (int i = 0; i < QB * 4; ++i) cxxv[i] = cxx_s[g][wc * QB * 4 + i];
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
         // accumulator register r of lane group g is candidate row 4 r + g of the block: registers 0, 1
@@ -574,43 +653,38 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
         for (int h = 0; h < 2; ++h) {
             const int b = b0 + (wc * QB + q) * 2 + h;
             const bool live = b < batch;
-            const float *prev = (live && has_prev) ? kpp_at(rows_prev0, st.rows_prev, b) + (size_t)selv[q][h] * n : nullptr;
-            float oldv[PB];
-#pragma unroll
-            for (int p = 0; p < PB; ++p) {
-                const int64_t i = row0 + (wp * PB + p) * 16 + j;
-                oldv[p] = (prev != nullptr && i < n) ? prev[i] : __builtin_inff();
-            }
-            double cxx[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) cxx[e] = (live && 4 * e + g < n_cand) ? kpp_at(cand_xx0, st.cand_xx, b)[4 * e + g] : 0.0;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int r = 2 * h + e, l = 4 * e + g;
                 const bool use = live && l < n_cand;  // uniform per 16-lane group
+                const double cxx = cxxv[q * 4 + h * 2 + e];
+                float *rows_out = kpp_at(rows_out0, st.rows_out, live ? b : 0) + (size_t)l * n;
                 double sum = 0.0;
-                if (use) {
-                    float *rows_out = kpp_at(rows_out0, st.rows_out, b) + (size_t)l * n;
 #pragma unroll
-                    for (int p = 0; p < PB; ++p) {
-                        const int64_t i = row0 + (wp * PB + p) * 16 + j;
-                        if (i < n) {
-                            double dd = -2.0 * acc[p][q][r];
-                            dd += cxx[e];
-                            dd += yyv[p];
-                            float f = (float)dd;
-                            f = f > 0.f ? f : 0.f;                    // np.maximum(d, 0)
-                            f = f < oldv[p] ? f : oldv[p];      // np.minimum(closest_dist_sq, distance_to_candidates)
-                            rows_out[i] = f;
-                            sum += (double)f;
-                        }
-                    }
+                for (int p = 0; p < PB; ++p) {
+                    const int64_t i = row0 + (wp * PB + p) * 16 + j;
+                    const bool ok = use && i < n;
+                    double dd = -2.0 * acc[p][q][r];
+                    dd += cxx;
+                    dd += yyv[p];
+                    float f = (float)dd;
+                    f = f > 0.f ? f : 0.f;                          // np.maximum(d, 0)
+                    f = f < oldv[q][h][p] ? f : oldv[q][h][p];      // np.minimum(closest_dist_sq, distance_to_candidates)
+                    if (ok) rows_out[i] = f;
+                    sum += ok ? (double)f : 0.0;
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
-                if (j == 0) part[wp][(wc * QB + q) * 16 + 8 * h + l] = sum;
+                sums[q * 4 + h * 2 + e] = sum;
             }
         }
+    }
+    kpp_row16_sums<QB * 4>(sums);
+    if (j == 0) {
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) part[wp][(wc * QB + q) * 16 + 8 * h + 4 * e + g] = sums[q * 4 + h * 2 + e];
     }
     __syncthreads();
     // block sums: the WP point slices of the workgroup in ascending order
