@@ -1062,7 +1062,32 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
     __shared__ double s_rand[KPP_MAX_L];
     __shared__ int s_blk[KPP_MAX_L];
     __shared__ double s_carry;
+    __shared__ double s_pot64[KPP_MAX_L];
+    __shared__ double s_u[KPP_MAX_L];
+    __shared__ int64_t s_cand[KPP_MAX_L];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // The kernel is a chain of dependent trips to memory (launch-bound: one workgroup per restart), so everything that
+    // does not depend on WHICH candidate wins is requested here, at the start, side by side: the double potentials of
+    // the contender test, the draws, the candidates' ids, the trailing points of the float32 sums, and -- when the
+    // block sums fit one pass (nblk <= 1024) and the candidate tile is the small one -- this thread's block sum of
+    // EVERY candidate row, of which (2a) keeps the winner's.  What remains dependent: the winner's points inside the
+    // drawn blocks (2b), then the drawn rows of X.
+    constexpr int PRE_L = 8;
+    const bool pre_bs = n_new > 0 && nblk <= 1024 && n_prev <= PRE_L;
+    double bsv[PRE_L];
+#pragma unroll
+    for (int l = 0; l < PRE_L; ++l) bsv[l] = (pre_bs && l < n_prev && tid < nblk) ? bsum_cur[(size_t)l * nblk + tid] : 0.0;
+    if (tid < n_prev) {
+        s_pot64[tid] = pot64[tid];
+        s_cand[tid] = cand[tid];
+    }
+    if (tid >= 64 && tid < 64 + n_new) s_u[tid - 64] = u[tid - 64];
+    float tailv[3] = {0.f, 0.f, 0.f};
+    if (pot_part != nullptr && tid < n_prev && pot_tail > 0) {
+        const float *tail = rows_cur + (size_t)tid * n + (n - pot_tail);
+        for (int e = 0; e < pot_tail; ++e) tailv[e] = tail[e];
+    }
 
     // (1) potentials: per candidate a thread-strided partial, a wave tree, then the 16 wave sums in order
     // (one barrier for all candidates; the additions and their order are those of a per-candidate loop)
@@ -1090,16 +1115,15 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
         // OpenBLAS order (see k_kpp_pot_blocks): y += block sum, block by block, then the n & 3 trailing points;
         // rows that cannot hold the smallest potential were not summed and are out of the argmin
         float y = __builtin_inff();
-        if (n_prev == 1 || kpp_contender(pot64, n_prev, tid, pot_eps)) {
+        if (n_prev == 1 || kpp_contender(s_pot64, n_prev, tid, pot_eps)) {
             y = 0.f;
             if (part_lds)
                 for (int b = 0; b < (int)pot_nb; ++b) y = y + s_part[tid * (int)pot_nb + b];
             else
                 for (int64_t b = 0; b < pot_nb; ++b) y = y + pot_part[(size_t)tid * pot_nb + b];
-            const float *tail = rows_cur + (size_t)tid * n + (n - pot_tail);
-            if (pot_tail == 3) y = y + ((tail[0] + tail[1]) + tail[2]);
-            else if (pot_tail == 2) y = y + (tail[0] + tail[1]);
-            else if (pot_tail == 1) y = y + tail[0];
+            if (pot_tail == 3) y = y + ((tailv[0] + tailv[1]) + tailv[2]);
+            else if (pot_tail == 2) y = y + (tailv[0] + tailv[1]);
+            else if (pot_tail == 1) y = y + tailv[0];
         }
         pots[tid] = y;
         }
@@ -1113,9 +1137,9 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
         s_sel = best;
         state[0] = best;
         pot_out[0] = pots[best];
-        index_out[0] = cand[best];
+        index_out[0] = s_cand[best];
         for (int l = 0; l < n_new; ++l) {
-            s_rand[l] = u[l] * (double)pots[best];  // random_state.uniform(size=L) * current_pot
+            s_rand[l] = s_u[l] * (double)pots[best];  // random_state.uniform(size=L) * current_pot
             s_blk[l] = 0;
         }
         s_carry = 0.0;
@@ -1130,7 +1154,13 @@ __global__ __launch_bounds__(1024) void k_kpp_select(const float *__restrict__ X
     // candidate count the blocks whose prefix is still below its draw (= index of its block)
     for (int64_t b0 = 0; b0 < nblk; b0 += 1024) {
         const int64_t b = b0 + tid;
-        double v = b < nblk ? bs[b] : 0.0;
+        double v = 0.0;
+        if (pre_bs) {  // this thread's block sum of every row came in at the start: keep the winner's
+#pragma unroll
+            for (int l = 0; l < PRE_L; ++l) v = sel == l ? bsv[l] : v;
+        } else if (b < nblk) {
+            v = bs[b];
+        }
         // wave inclusive scan
         for (int o = 1; o < 64; o <<= 1) {
             const double t = __shfl_up(v, o);

@@ -34,8 +34,8 @@ def test_batched_seeding_equals_single(n, d, k, b, gpu_device):
 @pytest.mark.parametrize("n,d,k,b", [(3001, 96, 40, 1), (2500, 128, 25, 3), (4099, 64, 30, 6), (3333, 96, 64, 20),
                                      (1500, 96, 16, 23)])
 def test_seeding_mfma_kernel_equals_fma_chain_kernel(n, d, k, b, gpu_device, monkeypatch):
-    """The scalar-operand vector kernel (the default) and the fp64-MFMA distance kernel (every instantiation: 1-2, 3-4, 5-8, 9+ restarts per workgroup column,
-    and more restarts than one column holds) against the multiply-add chain kernel it replaces: same
+    """The fp64-MFMA distance kernel (the default; both instantiations: 1-2 and 3-4 restarts per workgroup column, and more
+    restarts than one column holds) against the multiply-add chain kernel it replaces (MTP_KPP_KERNEL=fma): same
     seeds, same centres.  (tools/mfma_f64_order checks the instruction's accumulation order itself.)"""
     from pccs_accel import seeding
     X = datagen.make_encodings(300 + n, n, d, 9)
@@ -49,9 +49,9 @@ def test_seeding_mfma_kernel_equals_fma_chain_kernel(n, d, k, b, gpu_device, mon
     c_mfma, i_mfma = seeding.kmeans_plusplus_batched(Xc, k, draws)
     torch.cuda.synchronize()
     assert torch.equal(i_fma, i_mfma) and torch.equal(c_fma, c_mfma)
-    monkeypatch.delenv("MTP_KPP_KERNEL")  # the default: the scalar-operand vector kernel (k_kpp_dist_valu)
-    c_valu, i_valu = seeding.kmeans_plusplus_batched(Xc, k, draws)
-    assert torch.equal(i_fma, i_valu) and torch.equal(c_fma, c_valu)
+    monkeypatch.delenv("MTP_KPP_KERNEL")  # the default: the fp64-MFMA kernel
+    c_def, i_def = seeding.kmeans_plusplus_batched(Xc, k, draws)
+    assert torch.equal(i_fma, i_def) and torch.equal(c_fma, c_def)
     # and against the CPU oracle's replay of sklearn, restart 0
     oc, oi = O.kmeans_plusplus(np.ascontiguousarray(Xc.cpu().numpy()), k, np.random.RandomState(4))
     assert np.array_equal(i_mfma[0].cpu().numpy(), oi)
