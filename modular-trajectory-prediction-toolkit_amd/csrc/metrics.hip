@@ -88,6 +88,35 @@ __device__ __forceinline__ void candidate_dists(const T *__restrict__ p, const T
     last = l;
 }
 
+// The same arithmetic on a candidate whose HALF step pairs are already in registers (the software-pipelined path of
+// k_best_of_k: the loads of the NEXT candidate are in flight while this one is scored).
+template <typename T, bool DISP, int HALF>
+__device__ __forceinline__ void candidate_dists_regs(const typename Vec4<T>::type (&pv)[HALF],
+                                                     const typename Vec4<T>::type *__restrict__ gv, T &sum, T &last) {
+    typedef typename Vec4<T>::type V;
+    T s = 0, l = 0;
+    T cx = 0, cy = 0;
+#pragma unroll
+    for (int q = 0; q < HALF; ++q) {
+        V a = pv[q];
+        const V b = gv[q];
+        if (DISP) {
+            a.x = a.x + cx;
+            a.y = a.y + cy;
+            a.z = a.z + a.x;
+            a.w = a.w + a.y;
+            cx = a.z;
+            cy = a.w;
+        }
+        const T dx0 = b.x - a.x, dy0 = b.y - a.y, dx1 = b.z - a.z, dy1 = b.w - a.w;
+        const T d0 = tsqrt<T>(dx0 * dx0 + dy0 * dy0);
+        l = tsqrt<T>(dx1 * dx1 + dy1 * dy1);
+        s = (s + d0) + l;
+    }
+    sum = s;
+    last = l;
+}
+
 template <typename T>
 __device__ __forceinline__ void lexmin(T &v, int &i, T ov, int oi) {
     if (ov < v || (ov == v && oi < i)) {
@@ -100,7 +129,7 @@ __device__ __forceinline__ void lexmin(T &v, int &i, T ov, int oi) {
 // candidate c of agent a is pred[a, order[a, c]] -- the re-ranked candidate list of
 // verify_predictions.py:277-280 scored without materialising the re-ordered tensor; the
 // reported indices are positions c in that list.
-template <typename T, bool VEC, bool DISP>
+template <typename T, bool VEC, bool DISP, int HALF = 0>
 __global__ __launch_bounds__(256) void k_best_of_k(const T *__restrict__ pred, const T *__restrict__ gt, int64_t n,
                                                    int k, int kstride, int t, T ade_div, int mode, int apb,
                                                    const int32_t *__restrict__ order, int ostride,
@@ -117,6 +146,49 @@ __global__ __launch_bounds__(256) void k_best_of_k(const T *__restrict__ pred, c
         const int64_t a0 = grp * apb;
         const int na = (int)min((int64_t)apb, n - a0);
         // phase 1: per-candidate (ADE, FDE) -> LDS
+        if constexpr (HALF > 0) {
+            // t = 2 * HALF known at compile time (the reference predicts 12 steps): a candidate is HALF 16-byte (float)
+            // loads, all issued at once, and the candidate 256 places on is requested BEFORE this one is scored -- two
+            // candidates per lane in flight, so the memory pipe never runs dry while the square roots are refined
+            typedef typename Vec4<T>::type V;
+            const int total = na * k;
+            auto cand_ptr = [&](int c) -> const V * {
+                const int a = c / k, cand = c - a * k;
+                const int src = order ? order[(size_t)(a0 + a) * ostride + cand] : cand;
+                return reinterpret_cast<const V *>(pred + ((size_t)(a0 + a) * kstride + src) * tstride);
+            };
+            auto score = [&](int c, const V (&buf)[HALF]) {
+                const int a = c / k;
+                T s, l;
+                candidate_dists_regs<T, DISP, HALF>(buf, reinterpret_cast<const V *>(gt + (size_t)(a0 + a) * tstride), s, l);
+                s_ade[c] = s / ade_div;
+                s_fde[c] = l;
+            };
+            V b0[HALF], b1[HALF];
+            int c = tid;
+            if (c < total) {
+                const V *p = cand_ptr(c);
+#pragma unroll
+                for (int q = 0; q < HALF; ++q) b0[q] = p[q];
+            }
+            while (c < total) {
+                if (c + 256 < total) {
+                    const V *p = cand_ptr(c + 256);
+#pragma unroll
+                    for (int q = 0; q < HALF; ++q) b1[q] = p[q];
+                }
+                score(c, b0);
+                c += 256;
+                if (c >= total) break;
+                if (c + 256 < total) {
+                    const V *p = cand_ptr(c + 256);
+#pragma unroll
+                    for (int q = 0; q < HALF; ++q) b0[q] = p[q];
+                }
+                score(c, b1);
+                c += 256;
+            }
+        } else
         for (int c = tid; c < na * k; c += 256) {
             const int a = c / k, cand = c - a * k;
             const int src = order ? order[(size_t)(a0 + a) * ostride + cand] : cand;
@@ -212,12 +284,32 @@ static int best_of_k_impl(const T *pred, const T *gt, int64_t n, int k, int kstr
     if (apb < 1) apb = 1;
     const size_t lds = (size_t)apb * per_agent;
     const int64_t n_groups = (n + apb - 1) / apb;
-    const unsigned grid = (unsigned)(n_groups < 256 * 8 ? n_groups : 256 * 8);
     const bool vec = (t % 2 == 0) && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(gt)) % (4 * sizeof(T)) == 0);
+    // The software-pipelined instantiation (float, t = 12: the reference's pred_len) runs one workgroup per group of agents:
+    // 111 registers let a CU hold 4 of them, and handing the groups out one by one keeps every CU fed to the end
+    // (1.64 ms as a persistent grid of 2048, 1.60 ms this way at 1M x 100 x 12).  The other instantiations keep the
+    // persistent grid (two atomics per workgroup on the two sums).
+    // Short candidate lists (the re-ranked first 20: 2.5 candidates per lane and group) have nothing to pipeline and
+    // measured 12 % slower this way: they keep the plain loop.
+    const bool piped = vec && t == 12 && sizeof(T) == 4 && order == nullptr && (int64_t)apb * k >= 4 * 256;
+    const int64_t gmax = piped ? 0x7fffffff : 256 * 8;
+    const unsigned grid = (unsigned)(n_groups < gmax ? n_groups : gmax);
     hipStream_t s = mtp_stream(stream);
-#define MTP_BOK_LAUNCH(VEC, DISP)                                                                                   \
-    hipLaunchKernelGGL((k_best_of_k<T, VEC, DISP>), dim3(grid), dim3(256), lds, s, pred, gt, n, k, kstride, t, ade_div, \
-                       mode, apb, order, ostride, min_ade, min_fde, idx, idx2, sums)
+#define MTP_BOK_LAUNCH(VEC, DISP, ...)                                                                              \
+    hipLaunchKernelGGL((k_best_of_k<T, VEC, DISP, ##__VA_ARGS__>), dim3(grid), dim3(256), lds, s, pred, gt, n, k, kstride, t, \
+                       ade_div, mode, apb, order, ostride, min_ade, min_fde, idx, idx2, sums)
+    if constexpr (sizeof(T) == 4) {
+        if (piped && disp) {
+            MTP_BOK_LAUNCH(true, true, 6);
+            MTP_LAUNCH_CHECK();
+            return MTP_OK;
+        }
+        if (piped) {
+            MTP_BOK_LAUNCH(true, false, 6);
+            MTP_LAUNCH_CHECK();
+            return MTP_OK;
+        }
+    }
     if (vec && disp)
         MTP_BOK_LAUNCH(true, true);
     else if (vec)
