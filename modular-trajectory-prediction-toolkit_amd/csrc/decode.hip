@@ -35,10 +35,15 @@ __device__ __forceinline__ void decode_step(float x, float y, float &cx, float &
 }
 
 // t even, 16-byte aligned tensors.  cv = t/2 16-byte slots per candidate, LDS row stride rs (odd).
-__global__ __launch_bounds__(256) void k_decode_staged(const float *disp, int64_t total /* n*k */, int k, int cv, int rs,
+// CV > 0: cv as a compile-time constant (6 for the reference's 12 steps) -- a thread's CV loads of a tile are all issued
+// before the first of them is used, and the grid is one workgroup per tile (the dispatcher keeps every CU fed to the
+// end); CV = 0: any cv, persistent grid.
+template <int CV>
+__global__ __launch_bounds__(256) void k_decode_staged(const float *disp, int64_t total /* n*k */, int k, int cv_rt, int rs,
                                                        const float *__restrict__ rot,
                                                        const float *__restrict__ last_obs, float *out) {
     extern __shared__ __attribute__((aligned(16))) float4 tile[];  // 256 * rs slots
+    const int cv = CV > 0 ? CV : cv_rt;
     const int tid = threadIdx.x;
     const int64_t n_tiles = (total + 255) / 256;
     for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
@@ -47,9 +52,24 @@ __global__ __launch_bounds__(256) void k_decode_staged(const float *disp, int64_
         const int n_slots = nc * cv;
         const float4 *src = reinterpret_cast<const float4 *>(disp) + c0 * cv;
         float4 *dst = reinterpret_cast<float4 *>(out) + c0 * cv;
-        for (int e = tid; e < n_slots; e += 256) {
-            const int c = e / cv, q = e - c * cv;
-            tile[c * rs + q] = src[e];
+        if constexpr (CV > 0) {
+            float4 v[CV];
+#pragma unroll
+            for (int i = 0; i < CV; ++i) {
+                const int e = tid + 256 * i;
+                v[i] = src[e < n_slots ? e : n_slots - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < CV; ++i) {
+                const int e = tid + 256 * i;
+                const int c = e / CV, q = e - c * CV;
+                if (e < n_slots) tile[c * rs + q] = v[i];
+            }
+        } else {
+            for (int e = tid; e < n_slots; e += 256) {
+                const int c = e / cv, q = e - c * cv;
+                tile[c * rs + q] = src[e];
+            }
         }
         __syncthreads();
         if (tid < nc) {
@@ -65,7 +85,8 @@ __global__ __launch_bounds__(256) void k_decode_staged(const float *disp, int64_
             }
             float cx = 0.f, cy = 0.f;
             float4 *row = tile + tid * rs;
-            for (int q = 0; q < cv; ++q) {
+#pragma unroll
+            for (int q = 0; q < (CV > 0 ? CV : cv); ++q) {
                 const float4 v = row[q];
                 float4 w;
                 decode_step(v.x, v.y, cx, cy, rot != nullptr, m00, m01, m10, m11, last_obs != nullptr, lx, ly, w.x, w.y);
@@ -74,9 +95,18 @@ __global__ __launch_bounds__(256) void k_decode_staged(const float *disp, int64_
             }
         }
         __syncthreads();
-        for (int e = tid; e < n_slots; e += 256) {
-            const int c = e / cv, q = e - c * cv;
-            dst[e] = tile[c * rs + q];
+        if constexpr (CV > 0) {
+#pragma unroll
+            for (int i = 0; i < CV; ++i) {
+                const int e = tid + 256 * i;
+                const int c = e / CV, q = e - c * CV;
+                if (e < n_slots) dst[e] = tile[c * rs + q];
+            }
+        } else {
+            for (int e = tid; e < n_slots; e += 256) {
+                const int c = e / cv, q = e - c * cv;
+                dst[e] = tile[c * rs + q];
+            }
         }
         __syncthreads();
     }
@@ -157,9 +187,14 @@ extern "C" int mtp_decode_trajectories_f32(const float *disp, int64_t n, int k, 
     const size_t lds = (size_t)256 * rs * 16;
     if (vec && lds <= 64 * 1024) {
         int64_t tiles = (total + 255) / 256;
-        if (tiles > 256 * 8) tiles = 256 * 8;
-        hipLaunchKernelGGL(k_decode_staged, dim3((unsigned)tiles), dim3(256), lds, s, disp, total, k, cv, rs, rot, last_obs,
-                           out);
+        if (cv == 6 && tiles <= 0x7fffffff) {
+            hipLaunchKernelGGL(k_decode_staged<6>, dim3((unsigned)tiles), dim3(256), lds, s, disp, total, k, cv, rs, rot,
+                               last_obs, out);
+        } else {
+            if (tiles > 256 * 8) tiles = 256 * 8;
+            hipLaunchKernelGGL(k_decode_staged<0>, dim3((unsigned)tiles), dim3(256), lds, s, disp, total, k, cv, rs, rot,
+                               last_obs, out);
+        }
     } else if (vec)
         hipLaunchKernelGGL(k_decode_trajectories<true>, dim3((unsigned)blocks), dim3(256), 0, s, disp, n, k, t, rot,
                            last_obs, out);
