@@ -13,7 +13,22 @@
 // LDS adds (tuning ablation: load-only time).
 // DT: the feature size as a compile-time constant (0: any d, taken from the argument) -- row addresses and LDS
 // offsets then fold into immediates and shifts.
-template <int LPR, int G, typename ACC, bool DO_ADD, int DT = 0>
+// NT: the rows are fetched with non-temporal loads (every row is read by exactly one workgroup, once).
+template <bool NT>
+__device__ inline float4 acc_load16(const float *p) {
+    if constexpr (NT) {
+        float4 v;
+        v.x = __builtin_nontemporal_load(p);
+        v.y = __builtin_nontemporal_load(p + 1);
+        v.z = __builtin_nontemporal_load(p + 2);
+        v.w = __builtin_nontemporal_load(p + 3);
+        return v;
+    } else {
+        return *reinterpret_cast<const float4 *>(p);
+    }
+}
+
+template <int LPR, int G, typename ACC, bool DO_ADD, int DT = 0, bool NT = false>
 __global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X, int64_t n, int d_rt,
                                                      const int32_t *__restrict__ labels, int k, int kr,
                                                      int64_t rows_per_chunk, double *sums, double *counts,
@@ -94,7 +109,7 @@ __global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X
                 rn[g] = (b >= 0 && c0 < dq) ? r : -1;
                 pn[g] = X + (base + (b < 0 ? 0 : b)) * d;
                 vn[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rn[g] >= 0) vn[g] = reinterpret_cast<const float4 *>(pn[g])[c0];
+                if (rn[g] >= 0) vn[g] = acc_load16<NT>(pn[g] + 4 * c0);
             }
         }
         if (have_cur) {

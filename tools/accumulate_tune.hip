@@ -30,11 +30,11 @@ __global__ void k_labels(int32_t *p, size_t n, int k, unsigned seed) {
 
 struct Cfg { size_t lds_bytes; int threads; int max_wg; };
 
-template <int LPR, int G, typename ACC, bool DO_ADD>
+template <int LPR, int G, typename ACC, bool DO_ADD, int DT = 0, bool NT = false>
 void launch_v(const float *X, int64_t n, int d, const int32_t *labels, int k, double *sums, double *counts, Cfg c) {
     static bool set = false;
     if (!set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate<LPR, G, ACC, DO_ADD>),
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate<LPR, G, ACC, DO_ADD, DT, NT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         set = true;
     }
@@ -48,7 +48,7 @@ void launch_v(const float *X, int64_t n, int d, const int32_t *labels, int k, do
     int64_t rpc = (n + n_chunks - 1) / n_chunks;
     rpc = (rpc + 63) / 64 * 64;
     n_chunks = (n + rpc - 1) / rpc;
-    hipLaunchKernelGGL((k_accumulate<LPR, G, ACC, DO_ADD>), dim3((unsigned)n_chunks, (unsigned)n_ranges), dim3(c.threads),
+    hipLaunchKernelGGL((k_accumulate<LPR, G, ACC, DO_ADD, DT, NT>), dim3((unsigned)n_chunks, (unsigned)n_ranges), dim3(c.threads),
                        lds, 0, X, n, d, labels, k, kr, rpc, sums, counts, nullptr, mtp_no_batch());
     CK(hipGetLastError());
 }
@@ -77,6 +77,10 @@ int main(int argc, char **argv) {
     const Cfg big = {152 * 1024, 1024, 256}, half = {76 * 1024, 1024, 512}, half512 = {76 * 1024, 512, 512};
     std::vector<Variant> vs = {
         {"f64 G4 1024thr 152KB (product)", launch_v<32, 4, double, true>, big, true},
+        {"f64 G4 d=128 const", launch_v<32, 4, double, true, 128>, big, true},
+        {"f64 G4 d=128 const, nt rows", launch_v<32, 4, double, true, 128, true>, big, true},
+        {"f64 G8 d=128 const, nt rows", launch_v<32, 8, double, true, 128, true>, big, true},
+        {"f64 G4 no-add d=128 nt (load only)", launch_v<32, 4, double, false, 128, true>, big, false},
         {"f64 G8 1024thr 152KB", launch_v<32, 8, double, true>, big, true},
         {"f64 G8 no-add (load only)", launch_v<32, 8, double, false>, big, false},
         {"f64 G8 1024thr 76KB x2/CU", launch_v<32, 8, double, true>, half, true},
