@@ -664,8 +664,9 @@ __global__ __launch_bounds__(256, MINB) void k_kpp_dist_mfma(const float *__rest
                 for (int p = 0; p < PB; ++p) {
                     const int64_t i = row0 + (wp * PB + p) * 16 + j;
                     const bool ok = use && i < n;
-                    double dd = -2.0 * acc[p][q][r];
-                    dd += cxx;
+                    // -2 * dot is exact, so one fma gives the bits of sklearn's `d *= -2; d += XX` (two roundings, the
+                    // first of which changes nothing); the multiply-add chain kernel keeps the two-step form
+                    double dd = __builtin_fma(-2.0, acc[p][q][r], cxx);
                     dd += yyv[p];
                     float f = (float)dd;
                     f = f > 0.f ? f : 0.f;                          // np.maximum(d, 0)

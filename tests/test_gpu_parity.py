@@ -135,9 +135,11 @@ def test_get_modality_empty_cluster_keyerror(gpu_device):
         get_modality(torch.from_numpy(X), np.zeros(64, dtype=np.int32), 2)
 
 
-@pytest.mark.parametrize("n,d,k", [(1, 4, 1), (100, 12, 3), (5000, 96, 200), (3000, 128, 300), (999, 7, 5)])
+@pytest.mark.parametrize("n,d,k", [(1, 4, 1), (100, 12, 3), (5000, 96, 200), (3000, 128, 300), (999, 7, 5),
+                                   (4000, 96, 450), (2500, 64, 700), (3000, 32, 1300)])
 def test_centroid_sums_shapes(n, d, k, gpu_device):
-    """Ranges (K*D*8 > LDS), tiny inputs, d % 4 != 0 fallback."""
+    """Ranges (K*D*8 > LDS: the range kernel with its non-temporal row loads at d = 64 / 96 / 128 and with d as an
+    argument), tiny inputs, d % 4 != 0 fallback."""
     from pccs_accel import kernels as K
     X = datagen.make_encodings(n + d, n, d, 3)
     labels = np.random.RandomState(n).randint(0, k, size=n).astype(np.int32)
