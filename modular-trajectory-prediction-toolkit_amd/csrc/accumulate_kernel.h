@@ -8,12 +8,7 @@
 #pragma once
 #include "mtp_internal.h"
 
-// ACC = double (product) or float (tuning only): the LDS accumulator type.  G = groups of
-// 64/LPR rows whose loads are issued together before their LDS adds.  DO_ADD = false skips the
-// LDS adds (tuning ablation: load-only time).
-// DT: the feature size as a compile-time constant (0: any d, taken from the argument) -- row addresses and LDS
-// offsets then fold into immediates and shifts.
-// NT: the rows are fetched with non-temporal loads (every row is read by exactly one workgroup, once).
+// one 16-byte piece of a row; NT: a non-temporal load (the four scalar loads merge into one global_load_dwordx4 nt)
 template <bool NT>
 __device__ inline float4 acc_load16(const float *p) {
     if constexpr (NT) {
@@ -28,6 +23,13 @@ __device__ inline float4 acc_load16(const float *p) {
     }
 }
 
+// ACC = double (product) or float (tuning only): the LDS accumulator type.  G = groups of
+// 64/LPR rows whose loads are issued together before their LDS adds.  DO_ADD = false skips the
+// LDS adds (tuning ablation: load-only time).
+// DT: the feature size as a compile-time constant (0: any d, taken from the argument) -- row addresses and LDS
+// offsets then fold into immediates and shifts.
+// NT: the rows are fetched with non-temporal loads (a single run: every row is read once, by the one workgroup whose
+// cluster range holds its label; batched restarts read the rows once per restart and keep the plain loads).
 template <int LPR, int G, typename ACC, bool DO_ADD, int DT = 0, bool NT = false>
 __global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ X, int64_t n, int d_rt,
                                                      const int32_t *__restrict__ labels, int k, int kr,

@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: the HIP path (through the C-ABI) against the CPU oracle on seeded random shapes,
+for a bounded time.  Development aid, run on the MI355X box:
+
+    python tests/fuzz_gpu_parity.py [seconds] [seed]
+
+Not collected by pytest (the fixed-shape tests in tests/test_gpu_*.py are the suite); lives under tests/ because it
+imports the oracle, which is test infrastructure only.  Same bars as the suite: integer outputs bit-exact, sums to
+1e-12, centres / inertia / ADE / FDE to 1e-5 relative.  Prints one line per failing case and a summary; exit code 1
+if anything failed."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("modular-trajectory-prediction-toolkit_amd", "oracle", os.path.join("tests", "golden")):
+    sys.path.insert(0, os.path.join(ROOT, p))
+
+import datagen  # noqa: E402
+import glue_oracle as G  # noqa: E402
+import kmeans_oracle as O  # noqa: E402
+from pccs_accel import kernels as K  # noqa: E402
+from pccs_accel import seeding  # noqa: E402
+
+DEV = torch.device("cuda:0")
+FAIL = []
+COUNT = {}
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def check(cond, case, **info):
+    COUNT[case] = COUNT.get(case, 0) + 1
+    if not cond:
+        FAIL.append((case, info))
+        print("FAIL", case, info, flush=True)
+
+
+def pick_d(rs):
+    return int(rs.choice([64, 96, 128, 64, 96, 128, int(rs.randint(1, 41)), 4 * int(rs.randint(1, 60))]))
+
+
+def case_assign(rs):
+    n, d, k = int(rs.randint(1, 6000)), pick_d(rs), int(rs.randint(1, 320))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    C = X[rs.randint(0, n, size=k)].copy()
+    if rs.rand() < 0.3:  # exact duplicates among the centres: the lowest index must win
+        C[rs.randint(0, k)] = C[rs.randint(0, k)]
+    prev_h = rs.randint(-1, k, size=n).astype(np.int32)
+    prev = dev(prev_h)
+    nch = torch.zeros(1, dtype=torch.float64, device=DEV)
+    got = K.assign(dev(X), dev(C), labels=prev, n_changed=nch).cpu().numpy()
+    want = O.assign(X, C, backend="chain")
+    check(np.array_equal(got, want), "assign", n=n, d=d, k=k, mism=int((got != want).sum()))
+    check(int(nch.item()) == int((want != prev_h).sum()), "assign.n_changed", n=n, d=d, k=k)
+
+
+def case_sums(rs):
+    n, d, k = int(rs.randint(1, 8000)), pick_d(rs), int(rs.randint(1, 1500))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, 5, 1500, 700)
+    labels = rs.randint(0, k, size=n).astype(np.int32)
+    if rs.rand() < 0.3:
+        labels[:] = labels[0]  # everything in one cluster
+    sums, counts = K.centroid_sums(dev(X), dev(labels), k)
+    ws, wc = O.accumulate_f64(X, labels, k)
+    check(np.array_equal(counts.cpu().numpy(), wc), "sums.counts", n=n, d=d, k=k)
+    check(np.allclose(sums.cpu().numpy(), ws, rtol=1e-12, atol=1e-12), "sums", n=n, d=d, k=k)
+
+
+def case_lloyd(rs):
+    n, d, k = int(rs.randint(40, 2500)), int(rs.choice([64, 96, 128, 12, 20])), int(rs.randint(1, 40))
+    k = min(k, n)
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k), 1500, 700)
+    X = X - X.mean(0)
+    C0 = X[rs.choice(n, size=k, replace=False)].copy()
+    tol = float(O.tolerance(X)) if rs.rand() < 0.7 else 0.0
+    ce = int(rs.choice([1, 3, 8]))
+    labels, inertia, centers, n_iter = K.lloyd(dev(X), dev(C0), max_iter=60, tol_abs=tol, check_every=ce)
+    ol, oi, oc, on = O.kmeans_single_lloyd(X, C0, 60, tol, sums="f64")
+    info = dict(n=n, d=d, k=k, tol=tol, check_every=ce)
+    check(n_iter == on, "lloyd.n_iter", got=n_iter, want=on, **info)
+    check(np.array_equal(labels.cpu().numpy(), ol), "lloyd.labels", mism=int((labels.cpu().numpy() != ol).sum()), **info)
+    check(np.allclose(centers.cpu().numpy(), oc, rtol=1e-5, atol=1e-6), "lloyd.centers", **info)
+    check(np.isclose(inertia, oi, rtol=1e-5), "lloyd.inertia", got=inertia, want=float(oi), **info)
+    # the batched path, the same run three times over with one different start
+    if k >= 2 and d in (64, 96, 128) and rs.rand() < 0.5:  # the batched entry takes the MFMA feature sizes only
+        C1 = X[rs.choice(n, size=k, replace=False)].copy()
+        bl, bi, bc, bn = K.lloyd_batched(dev(X), dev(np.stack([C0, C1, C0])), max_iter=60, tol_abs=tol, check_every=ce)
+        check(bn[0] == on and bn[2] == on, "lloyd_batched.n_iter", got=bn, want=on, **info)
+        check(np.array_equal(bl[0].cpu().numpy(), ol) and np.array_equal(bl[2].cpu().numpy(), ol), "lloyd_batched.labels", **info)
+        l1, i1, c1, n1 = K.lloyd(dev(X), dev(C1), max_iter=60, tol_abs=tol, check_every=ce)
+        check(bn[1] == n1 and torch.equal(bl[1], l1) and torch.equal(bc[1], c1), "lloyd_batched.second", **info)
+
+
+def case_best_of_k(rs):
+    n, k = int(rs.randint(1, 3000)), int(rs.randint(1, 130))
+    t = int(rs.choice([12, 12, 12, 8, 5, 1, 20]))
+    dt = np.float32 if rs.rand() < 0.7 else np.float64
+    pred, gt = datagen.make_trajectories(int(rs.randint(1 << 30)), n, k, t, dtype=dt)
+    if k > 1 and rs.rand() < 0.5:  # exact ties: a duplicated candidate
+        a = rs.randint(0, n, size=max(1, n // 4))
+        pred[a, rs.randint(0, k)] = pred[a, rs.randint(0, k)]
+    mode = int(rs.randint(0, 3))
+    best_of = None if rs.rand() < 0.6 else int(rs.randint(1, k + 1))
+    g = K.best_of_k(dev(pred), dev(gt), mode=mode, best_of=best_of)
+    o = O.best_of_k(pred, gt, mode=mode, best_of=best_of)
+    info = dict(n=n, k=k, t=t, dt=dt.__name__, mode=mode, best_of=best_of)
+    check(np.array_equal(g["idx"].cpu().numpy(), o["idx"]), "best_of_k.idx", **info)
+    check(np.array_equal(g["idx2"].cpu().numpy(), o["idx2"]), "best_of_k.idx2", **info)
+    check(np.allclose(g["min_ade"].cpu().numpy(), o["min_ade"], rtol=1e-5, atol=0), "best_of_k.min_ade", **info)
+    check(np.allclose(g["min_fde"].cpu().numpy(), o["min_fde"], rtol=1e-5, atol=0), "best_of_k.min_fde", **info)
+    s = g["sums"].cpu().numpy()
+    check(np.isclose(s[0], o["sum_ade"], rtol=1e-9) and np.isclose(s[1], o["sum_fde"], rtol=1e-9), "best_of_k.sums", **info)
+
+
+def case_decode(rs):
+    n, k, t = int(rs.randint(1, 600)), int(rs.randint(1, 40)), int(rs.choice([12, 12, 8, 7, 1]))
+    disp = datagen.make_displacements(int(rs.randint(1 << 30)), n, k, t)
+    th = rs.rand(n).astype(np.float32) * 6.28 - 3.14
+    rot = np.stack([np.stack([np.cos(th), -np.sin(th)], -1), np.stack([np.sin(th), np.cos(th)], -1)], 1).astype(np.float32)
+    last = rs.randn(n, 2).astype(np.float32)
+    use_rot = rs.rand() < 0.6
+    info = dict(n=n, k=k, t=t, rot=use_rot)
+    if use_rot:
+        got = K.decode_trajectories(dev(disp), dev(rot), dev(last)).cpu().numpy()
+        want = G.decode_predictions(disp, rot, last)
+        check(np.array_equal(got, want), "decode.rot", maxdiff=float(np.abs(got - want).max()), **info)
+    else:
+        got = K.decode_trajectories(dev(disp)).cpu().numpy()
+        want = G.transform_trajectory(disp)
+        check(np.array_equal(got, want), "decode.cumsum", **info)
+    # fused displacement scoring == decode then score
+    gt = datagen.make_trajectories(int(rs.randint(1 << 30)), n, 1, t)[1]
+    mode = int(rs.randint(0, 3))
+    a = K.best_of_k_disp(dev(disp), dev(gt), mode=mode)
+    b = K.best_of_k(K.decode_trajectories(dev(disp)), dev(gt), mode=mode)
+    check(torch.equal(a["idx"], b["idx"]) and torch.equal(a["min_ade"], b["min_ade"]) and torch.equal(a["min_fde"], b["min_fde"]),
+          "best_of_k_disp", mode=mode, **info)
+
+
+def case_nms(rs):
+    n, m, t = int(rs.randint(1, 200)), int(rs.randint(2, 64)), 12
+    dt = np.float64 if rs.rand() < 0.6 else np.float32
+    pred, _, sc32 = datagen.make_candidate_sets(int(rs.randint(1 << 30)), n, m, t, dtype=dt)
+    scores = sc32.astype(np.float64) if rs.rand() < 0.5 else sc32
+    max_samples = int(rs.randint(1, m + 1))
+    best_of = int(rs.randint(1, max_samples + 1))
+    thresh = float(rs.choice([0.1, 0.3, 1.0]))
+    order, n_sel = K.nms_rerank(dev(pred), dev(scores), max_samples, best_of, 2, thresh)
+    worder, wsel, wout = G.nms_rerank(pred, scores, max_samples, best_of, 2, thresh)
+    info = dict(n=n, m=m, dt=dt.__name__, sdt=scores.dtype.name, max_samples=max_samples, best_of=best_of, thresh=thresh)
+    check(np.array_equal(order.cpu().numpy(), worder), "nms_rerank.order", **info)
+    check(np.array_equal(n_sel.cpu().numpy(), wsel), "nms_rerank.n_selected", **info)
+    check(np.array_equal(K.gather_candidates(dev(pred), order).cpu().numpy(), wout), "gather_candidates", **info)
+
+
+def case_relocation(rs):
+    """Centres far outside the data start empty: sklearn's relocation (far points in descending distance here)."""
+    n, d, k = int(rs.randint(60, 2500)), int(rs.choice([64, 96, 128, 12])), int(rs.randint(3, 40))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    X = X - X.mean(0)
+    C0 = X[rs.choice(n, size=k, replace=False)].copy()
+    n_far = int(rs.randint(1, k))
+    C0[rs.choice(k, size=n_far, replace=False)] += np.float32(50.0)
+    tol = float(O.tolerance(X))
+    ce = int(rs.choice([1, 4]))
+    labels, inertia, centers, n_iter = K.lloyd(dev(X), dev(C0), max_iter=40, tol_abs=tol, check_every=ce)
+    ol, oi, oc, on = O.kmeans_single_lloyd(X, C0, 40, tol, sums="f64", far_order="descending")
+    info = dict(n=n, d=d, k=k, n_far=n_far, check_every=ce)
+    check(n_iter == on, "relocation.n_iter", got=n_iter, want=on, **info)
+    check(np.array_equal(labels.cpu().numpy(), ol), "relocation.labels", mism=int((labels.cpu().numpy() != ol).sum()), **info)
+    check(np.allclose(centers.cpu().numpy(), oc, rtol=1e-5, atol=1e-6), "relocation.centers", **info)
+    check(np.isclose(inertia, oi, rtol=1e-5), "relocation.inertia", **info)
+
+
+def case_seeding(rs):
+    n, d = int(rs.randint(50, 9000)), int(rs.choice([64, 96, 128, 12, 20, 32]))
+    k = int(rs.randint(1, min(n, 48) + 1))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(2, k), 1500, 700)
+    X = X - X.mean(0)
+    seed = int(rs.randint(1 << 30))
+    _, idx = seeding.kmeans_plusplus(dev(X), k, np.random.RandomState(seed))
+    _, widx = O.kmeans_plusplus(X, k, np.random.RandomState(seed))
+    info = dict(n=n, d=d, k=k, seed=seed)
+    got = idx.cpu().numpy()
+    check(np.array_equal(got, widx), "seeding.indices", first_diff=int(np.argmax(got != widx)) if (got != widx).any() else -1, **info)
+    # three restarts in shared launches == one at a time, from the same stream of draws
+    r1, r2 = np.random.RandomState(seed), np.random.RandomState(seed)
+    draws = [seeding.draw(r1, n, k) for _ in range(3)]
+    _, bidx = seeding.kmeans_plusplus_batched(dev(X), k, draws)
+    singles = [seeding.kmeans_plusplus(dev(X), k, r2)[1] for _ in range(3)]
+    check(all(torch.equal(bidx[i], singles[i]) for i in range(3)), "seeding.batched", **info)
+
+
+CASES = [case_assign, case_sums, case_lloyd, case_best_of_k, case_decode, case_nms, case_relocation, case_seeding]
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rs = np.random.RandomState(seed)
+    t0 = time.time()
+    rounds = 0
+    last_print = t0
+    while time.time() - t0 < budget:
+        for c in CASES:
+            sub = np.random.RandomState(rs.randint(1 << 31))
+            try:
+                c(sub)
+            except Exception as exc:  # noqa: BLE001  (an unexpected refusal is a finding too)
+                FAIL.append((c.__name__, repr(exc)))
+                print("EXC", c.__name__, repr(exc), flush=True)
+        rounds += 1
+        if time.time() - last_print > 20:
+            last_print = time.time()
+            print(f"... {rounds} rounds, {sum(COUNT.values())} checks, {len(FAIL)} failures", flush=True)
+    print(f"fuzz: seed {seed}, {rounds} rounds, {sum(COUNT.values())} checks over {len(COUNT)} kinds, {len(FAIL)} failures")
+    for kname in sorted(COUNT):
+        print(f"  {kname}: {COUNT[kname]}")
+    sys.exit(1 if FAIL else 0)
+
+
+if __name__ == "__main__":
+    main()
