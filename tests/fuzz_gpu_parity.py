@@ -197,7 +197,35 @@ def case_seeding(rs):
     check(all(torch.equal(bidx[i], singles[i]) for i in range(3)), "seeding.batched", **info)
 
 
-CASES = [case_assign, case_sums, case_lloyd, case_best_of_k, case_decode, case_nms, case_relocation, case_seeding]
+def case_one_thread_mode(rs):
+    """sums="sklearn_1t": float32 row-order chains, float32 shift sum and inertia chain -- sklearn on one thread."""
+    n, d, k = int(rs.randint(40, 2000)), int(rs.choice([64, 96, 128, 20, 200])), int(rs.randint(1, 30))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k), 1500, 700)
+    X = X - X.mean(0)
+    C0 = X[rs.choice(n, size=k, replace=False)].copy()
+    if k >= 3 and rs.rand() < 0.4:
+        C0[rs.choice(k, size=int(rs.randint(1, k - 1)), replace=False)] += np.float32(50.0)  # empty at first: relocation
+    tol = float(O.tolerance(X))
+    labels, inertia, centers, n_iter = K.lloyd(dev(X), dev(C0), max_iter=40, tol_abs=tol, check_every=1, sums="sklearn_1t")
+    ol, oi, oc, on = O.kmeans_single_lloyd(X, C0, 40, tol, sums="f32", far_order="descending", inertia_order="f32_chain")
+    info = dict(n=n, d=d, k=k)
+    check(n_iter == on, "one_thread.n_iter", got=n_iter, want=on, **info)
+    check(np.array_equal(labels.cpu().numpy(), ol), "one_thread.labels", **info)
+    check(np.array_equal(centers.cpu().numpy(), oc), "one_thread.centers_bits", **info)
+    check(np.float32(inertia) == np.float32(oi), "one_thread.inertia_bits", got=float(inertia), want=float(oi), **info)
+
+
+def case_targets(rs):
+    n, k = int(rs.randint(1, 5000)), int(rs.randint(1, 450))
+    labels = rs.randint(0, k, size=n).astype(np.int32)
+    ll, oh = K.label_targets(dev(labels), k)
+    wl, wo = O.classifier_targets(labels, k)
+    check(np.array_equal(ll.cpu().numpy(), np.asarray(wl)) and ll.dtype == torch.int64, "targets.long", n=n, k=k)
+    check(np.array_equal(oh.cpu().numpy(), np.asarray(wo)), "targets.one_hot", n=n, k=k)
+
+
+CASES = [case_assign, case_sums, case_lloyd, case_best_of_k, case_decode, case_nms, case_relocation, case_seeding,
+         case_one_thread_mode, case_targets]
 
 
 def main():
