@@ -224,8 +224,42 @@ def case_targets(rs):
     check(np.array_equal(oh.cpu().numpy(), np.asarray(wo)), "targets.one_hot", n=n, k=k)
 
 
+def case_large(rs):
+    """Sizes that fill the chip: several rounds of E-step workgroups plus the split-launch tail, cluster ranges in the
+    sums, and a 20-restart batched fit through the restart-grouped E-step (every restart against the oracle)."""
+    d = int(rs.choice([64, 96, 128]))
+    n, k = int(rs.randint(100_000, 400_000)), int(rs.randint(100, 1100))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, 64, 1500, 700)
+    C = X[rs.randint(0, n, size=k)].copy()
+    got = K.assign(dev(X), dev(C)).cpu().numpy()
+    want = O.assign(X, C, backend="chain")
+    check(np.array_equal(got, want), "large.assign", n=n, d=d, k=k, mism=int((got != want).sum()))
+    sums, counts = K.centroid_sums(dev(X), dev(want), k)
+    ws, wc = O.accumulate_f64(X, want, k)
+    check(np.array_equal(counts.cpu().numpy(), wc) and np.allclose(sums.cpu().numpy(), ws, rtol=1e-12, atol=1e-12),
+          "large.sums", n=n, d=d, k=k)
+    nb, kb, b = int(rs.randint(5_000, 30_000)), int(rs.randint(20, 230)), int(rs.choice([5, 12, 20]))
+    Xb = datagen.make_encodings(int(rs.randint(1 << 30)), nb, d, kb, 1500, 700)
+    Xb = Xb - Xb.mean(0)
+    tol = float(O.tolerance(Xb))
+    C0s = np.stack([Xb[rs.choice(nb, size=kb, replace=False)] for _ in range(b)])
+    bl, bi, bc, bn = K.lloyd_batched(dev(Xb), dev(C0s), max_iter=25, tol_abs=tol, check_every=4)
+    bl, bi = bl.cpu().numpy(), bi.cpu().numpy()
+    ok_iter = ok_lab = ok_in = True
+    for r in range(b):
+        ol, oi, oc, on = O.kmeans_single_lloyd(Xb, C0s[r], 25, tol, sums="f64", far_order="descending")
+        ok_iter &= (bn[r] == on)
+        ok_lab &= bool(np.array_equal(bl[r], ol))
+        ok_in &= bool(np.isclose(bi[r], oi, rtol=1e-6))
+    info = dict(n=nb, d=d, k=kb, restarts=b)
+    check(ok_iter, "large.batched.n_iter", **info)
+    check(ok_lab, "large.batched.labels", **info)
+    check(ok_in, "large.batched.inertia", **info)
+
+
 CASES = [case_assign, case_sums, case_lloyd, case_best_of_k, case_decode, case_nms, case_relocation, case_seeding,
          case_one_thread_mode, case_targets]
+RARE = [case_large]  # every tenth round
 
 
 def main():
@@ -236,7 +270,7 @@ def main():
     rounds = 0
     last_print = t0
     while time.time() - t0 < budget:
-        for c in CASES:
+        for c in CASES + (RARE if rounds % 10 == 0 else []):
             sub = np.random.RandomState(rs.randint(1 << 31))
             try:
                 c(sub)
