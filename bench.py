@@ -116,11 +116,15 @@ def sklearn_baseline(Xs, C0, k, d, threads):
         from threadpoolctl import threadpool_limits
     except Exception:  # noqa: BLE001
         return None
-    with warnings.catch_warnings(), threadpool_limits(limits=threads):
-        warnings.simplefilter("ignore")
-        t0 = time.perf_counter()
-        km = KMeans(n_clusters=k, init=C0, n_init=1, max_iter=2, tol=0).fit(Xs)
-        dt = time.perf_counter() - t0
+    try:
+        with warnings.catch_warnings(), threadpool_limits(limits=threads):
+            warnings.simplefilter("ignore")
+            t0 = time.perf_counter()
+            km = KMeans(n_clusters=k, init=C0, n_init=1, max_iter=2, tol=0).fit(Xs)
+            dt = time.perf_counter() - t0
+    except Exception as exc:  # noqa: BLE001  (the oracle port then stands in as the CPU baseline)
+        print(f"bench.py: sklearn baseline at {threads} threads failed: {exc!r}", file=sys.stderr)
+        return None
     # 2 Lloyd iterations + the final E-step = 3 distance passes
     return {"value": 3 * Xs.shape[0] * k * d / dt, "unit": "distance-evals/s", "cores": threads, "kind": "reference",
             "sample": f"sklearn KMeans(init=C0, n_init=1, max_iter=2) on the first {Xs.shape[0]} points of the workload, "
@@ -533,43 +537,47 @@ def main():
         # StimulusVerification/verify_predictions.py:238-248 (float64, best of the first 20), both restated in
         # oracle/glue_oracle.py; the oracle's scalar C port is what the parity gate compares with
         if world == 1 and not args.no_cpu:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import glue_oracle as G
-            import kmeans_oracle as O
-            nt = min(20_000, ehi - elo)
-            pt, gtt = pred[:nt].cpu(), gt[:nt].cpu()
-            torch_threads = torch.get_num_threads()
-            t0 = time.perf_counter()
-            tv = G.evaluate_loop_torch(pt, gtt, mode=0)
-            tdt = time.perf_counter() - t0
-            out["best_of_k"]["cpu_baseline"] = {
-                "value": nt * float(args.eval_k) / tdt, "unit": "traj/s", "cores": torch_threads, "kind": "port",
-                "sample": f"the reference's evaluate loop (train_steps.py:214-232: one agent at a time, torch CPU ops, "
-                          f".item() per agent) on the first {nt} agents, mode 0; {tdt:.2f} s",
-                "mean_ade_fde": [float(tv[0]), float(tv[1])]}
-            nv = min(100_000, ehi - elo)
-            p64, g64 = pred[:nv, :20].cpu().numpy().astype(np.float64), gt[:nv].cpu().numpy().astype(np.float64)
-            t0 = time.perf_counter()
-            G.verify_best_of_numpy(p64, g64, best_of=20)
-            vdt = time.perf_counter() - t0
-            out["best_of_k"]["cpu_baseline_numpy"] = {
-                "value": nv * 20.0 / vdt, "unit": "traj/s", "cores": 1, "kind": "port",
-                "sample": f"verify_predictions.py:238-248 (np.linalg.norm + Python loop over agents, float64) on the first "
-                          f"{nv} agents x best-of-20; {vdt:.2f} s"}
-            del p64, g64
-            ns = min(1_000_000, ehi - elo)
-            ph, gh = pred[:ns].cpu().numpy(), gt[:ns].cpu().numpy()
-            t0 = time.perf_counter()
-            o = O.best_of_k(ph, gh, mode=0)
-            cdt = time.perf_counter() - t0
-            g = K.best_of_k(pred[:ns], gt[:ns], mode=0)
-            out["best_of_k"]["cpu_baseline_port"] = {
-                "value": ns * float(args.eval_k) / cdt, "unit": "traj/s", "cores": 1, "kind": "port",
-                "sample": f"oracle.c best-of-K (scalar, one thread) on the first {ns} agents, mode 0; {cdt:.2f} s"}
-            out["best_of_k"]["parity"] = {
-                "sample_agents": int(ns), "argmin_mismatches_vs_cpu_oracle": int((g["idx"].cpu().numpy() != o["idx"]).sum()),
-                "max_rel_err_min_ade": float(np.max(np.abs(g["min_ade"].cpu().numpy() - o["min_ade"]) / np.maximum(o["min_ade"], 1e-30))),
-                "torch_loop_mean_ade_rel_err": float(abs(tv[0] - float(K.best_of_k(pred[:nt], gt[:nt], mode=0)["sums"][0].item()) / nt) / tv[0])}
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import glue_oracle as G
+                import kmeans_oracle as O
+                nt = min(20_000, ehi - elo)
+                pt, gtt = pred[:nt].cpu(), gt[:nt].cpu()
+                torch_threads = torch.get_num_threads()
+                t0 = time.perf_counter()
+                tv = G.evaluate_loop_torch(pt, gtt, mode=0)
+                tdt = time.perf_counter() - t0
+                out["best_of_k"]["cpu_baseline"] = {
+                    "value": nt * float(args.eval_k) / tdt, "unit": "traj/s", "cores": torch_threads, "kind": "port",
+                    "sample": f"the reference's evaluate loop (train_steps.py:214-232: one agent at a time, torch CPU ops, "
+                              f".item() per agent) on the first {nt} agents, mode 0; {tdt:.2f} s",
+                    "mean_ade_fde": [float(tv[0]), float(tv[1])]}
+                nv = min(100_000, ehi - elo)
+                p64, g64 = pred[:nv, :20].cpu().numpy().astype(np.float64), gt[:nv].cpu().numpy().astype(np.float64)
+                t0 = time.perf_counter()
+                G.verify_best_of_numpy(p64, g64, best_of=20)
+                vdt = time.perf_counter() - t0
+                out["best_of_k"]["cpu_baseline_numpy"] = {
+                    "value": nv * 20.0 / vdt, "unit": "traj/s", "cores": 1, "kind": "port",
+                    "sample": f"verify_predictions.py:238-248 (np.linalg.norm + Python loop over agents, float64) on the first "
+                              f"{nv} agents x best-of-20; {vdt:.2f} s"}
+                del p64, g64
+                ns = min(1_000_000, ehi - elo)
+                ph, gh = pred[:ns].cpu().numpy(), gt[:ns].cpu().numpy()
+                t0 = time.perf_counter()
+                o = O.best_of_k(ph, gh, mode=0)
+                cdt = time.perf_counter() - t0
+                g = K.best_of_k(pred[:ns], gt[:ns], mode=0)
+                out["best_of_k"]["cpu_baseline_port"] = {
+                    "value": ns * float(args.eval_k) / cdt, "unit": "traj/s", "cores": 1, "kind": "port",
+                    "sample": f"oracle.c best-of-K (scalar, one thread) on the first {ns} agents, mode 0; {cdt:.2f} s"}
+                out["best_of_k"]["parity"] = {
+                    "sample_agents": int(ns), "argmin_mismatches_vs_cpu_oracle": int((g["idx"].cpu().numpy() != o["idx"]).sum()),
+                    "max_rel_err_min_ade": float(np.max(np.abs(g["min_ade"].cpu().numpy() - o["min_ade"]) / np.maximum(o["min_ade"], 1e-30))),
+                    "torch_loop_mean_ade_rel_err": float(abs(tv[0] - float(K.best_of_k(pred[:nt], gt[:nt], mode=0)["sums"][0].item()) / nt) / tv[0])}
+            except Exception as exc:  # noqa: BLE001  (a CPU leg that fails is reported, the GPU numbers stay)
+                out["best_of_k"]["cpu_baseline_error"] = repr(exc)
+                print(f"bench.py: best-of-K CPU legs failed: {exc!r}", file=sys.stderr)
         del pred, gt
 
     # ---- CPU baseline on a bounded sample (rank 0, N = 1 only) ----
@@ -602,7 +610,9 @@ def main():
             sk8["iters_per_s_full_n"] = sk8["value"] / (float(n) * k * d)
             out["cpu_baseline"] = sk8
             if cores > 8:
-                out["cpu_baseline_all_cores"] = sklearn_baseline(Xs, C0h, k, d, cores)
+                sk_all = sklearn_baseline(Xs, C0h, k, d, cores)
+                if sk_all is not None:
+                    out["cpu_baseline_all_cores"] = sk_all
             out["cpu_baseline_port"] = port
         else:
             out["cpu_baseline"] = port
@@ -614,13 +624,15 @@ def main():
         del X
         torch.cuda.empty_cache()
         # BASELINE configs 0-2: the five ETH/UCY leave-one-out splits (train / val sizes of SURVEY.md 8) and SDD
-        out["reference_configs"] = {
-            "eth": reference_config("eth split", 73_568, 200, 2_614, 10, device, not args.no_cpu),
-            "hotel": reference_config("hotel split", 76_646, 200, 1_075, 11, device, not args.no_cpu),
-            "univ": reference_config("univ split", 30_128, 200, 24_334, 12, device, not args.no_cpu),
-            "zara1": reference_config("zara1 split", 74_084, 200, 2_356, 13, device, not args.no_cpu),
-            "zara2": reference_config("zara2 split", 66_976, 200, 5_910, 14, device, not args.no_cpu),
-            "sdd": reference_config("SDD", 17_970, 400, 2_829, 20, device, not args.no_cpu)}
+        out["reference_configs"] = {}
+        for key, cfg in (("eth", ("eth split", 73_568, 200, 2_614, 10)), ("hotel", ("hotel split", 76_646, 200, 1_075, 11)),
+                         ("univ", ("univ split", 30_128, 200, 24_334, 12)), ("zara1", ("zara1 split", 74_084, 200, 2_356, 13)),
+                         ("zara2", ("zara2 split", 66_976, 200, 5_910, 14)), ("sdd", ("SDD", 17_970, 400, 2_829, 20))):
+            try:
+                out["reference_configs"][key] = reference_config(*cfg, device, not args.no_cpu)
+            except Exception as exc:  # noqa: BLE001  (a failed extra must not take the headline line with it; it is reported)
+                out["reference_configs"][key] = {"error": repr(exc)}
+                print(f"bench.py: reference config {key} failed: {exc!r}", file=sys.stderr)
 
     if rank == 0:
         real_stdout.write(json.dumps(out) + "\n")
