@@ -434,9 +434,12 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_assign_mfma_grouped(const float
                         ++cur_r;
                         cur_end += kp;
                     }
+                    // re-open at the restart's own first row (a live restart's first tile is live, so this quad IS that
+                    // row): a point that no distance beats -- NaN input -- still gets a label inside its restart's
+                    // range (0) and not a negative one
                     best = __builtin_inff();
-                    breg = 0;
-                    btile = 0;
+                    breg = 4 * g;
+                    btile = tile;
                     before = best;
                 }
                 if (cur_r < rg && ((live >> cur_r) & 1u)) {
