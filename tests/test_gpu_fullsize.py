@@ -152,3 +152,51 @@ def test_best_of_k_fullsize_properties(gpu_device):
         w = O.best_of_k(pred[lo:hi].cpu().numpy(), gt[lo:hi].cpu().numpy(), mode=0)
         assert np.array_equal(r0["idx"][lo:hi].cpu().numpy(), w["idx"])
         assert np.allclose(r0["min_ade"][lo:hi].cpu().numpy(), w["min_ade"], rtol=1e-6)
+
+
+def test_more_than_2_31_elements(gpu_device):
+    """N * D beyond 2^31 elements (36M x 64 = 2.3e9 floats, 9.2 GB): every row offset must be 64-bit.  E-step slices
+    at the head, across the 2^31-element line and at the ragged tail against the oracle; sums, column sums, inertia and
+    the in-place centring through linearity between the whole array and its two halves."""
+    from pccs_accel import kernels as Kn
+    n, d, k = 36_000_003, 64, 300
+    g = torch.Generator(device=gpu_device)
+    g.manual_seed(11)
+    M = torch.randn(k, d, generator=g, device=gpu_device) * 0.5
+    X = torch.empty((n, d), dtype=torch.float32, device=gpu_device)
+    for s in range(0, n, 1 << 21):
+        e = min(n, s + (1 << 21))
+        z = torch.randint(0, k, (e - s,), generator=g, device=gpu_device)
+        X[s:e] = torch.tanh(M[z] + 0.15 * torch.randn(e - s, d, generator=g, device=gpu_device))
+    C = X[torch.randperm(1 << 20, generator=torch.Generator().manual_seed(1))[:k].to(gpu_device)].contiguous()
+    line = (1 << 31) // d  # the row whose first element is element 2^31
+    labels = Kn.assign(X, C)
+    assert int(labels.min()) >= 0 and int(labels.max()) < k
+    Ch = C.cpu().numpy()
+    for lo, hi in ((0, 10000), (line - 5000, line + 5000), (n - 7777, n)):
+        want = O.assign(X[lo:hi].cpu().numpy(), Ch, backend="chain")
+        assert np.array_equal(labels[lo:hi].cpu().numpy(), want), (lo, hi)
+    # sums / counts: whole = head + tail, cut just below the line
+    cut = line - 12345
+    s_all, c_all = Kn.centroid_sums(X, labels, k)
+    s_h, c_h = Kn.centroid_sums(X[:cut], labels[:cut].contiguous(), k)
+    s_t, c_t = Kn.centroid_sums(X[cut:], labels[cut:].contiguous(), k)
+    assert int(c_all.sum().item()) == n and torch.equal(c_all, c_h + c_t)
+    assert torch.allclose(s_all, s_h + s_t, rtol=1e-12, atol=1e-9)
+    ws, wc = O.accumulate_f64(X[n - 50000:].cpu().numpy(), labels[n - 50000:].cpu().numpy(), k)
+    s_e, c_e = Kn.centroid_sums(X[n - 50000:], labels[n - 50000:].contiguous(), k)
+    assert np.array_equal(c_e.cpu().numpy(), wc) and np.allclose(s_e.cpu().numpy(), ws, rtol=1e-12, atol=1e-12)
+    # column sums and inertia the same way
+    col = Kn.col_sums(X)
+    assert torch.allclose(col, Kn.col_sums(X[:cut]) + Kn.col_sums(X[cut:]), rtol=1e-12, atol=1e-9)
+    i_all = Kn.inertia(X, C, labels)
+    i_parts = Kn.inertia(X[:cut], C, labels[:cut].contiguous()) + Kn.inertia(X[cut:], C, labels[cut:].contiguous())
+    assert torch.allclose(torch.as_tensor(i_all, dtype=torch.float64), torch.as_tensor(i_parts, dtype=torch.float64), rtol=1e-12)
+    # in-place centring: the rows beyond the line move by the mean too
+    mean = (col / n).to(torch.float32)
+    tail_before = X[n - 1000:].clone()
+    mid_before = X[line - 500:line + 500].clone()
+    Kn.sub_rowvec_(X, mean)
+    assert torch.equal(X[n - 1000:], tail_before - mean) and torch.equal(X[line - 500:line + 500], mid_before - mean)
+    del X
+    torch.cuda.empty_cache()
