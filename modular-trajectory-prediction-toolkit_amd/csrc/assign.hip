@@ -152,6 +152,17 @@ static int launch_assign_mfma(const float *X, int64_t n, const float *staged, in
     if (rc != MTP_OK) return rc;
     const int64_t per_round = (int64_t)2 * cus * 256;  // points
     const int64_t n_main = n / per_round * per_round;
+    {
+        // The split is only worth a second launch where it shortens the tail: left in the single launch the last,
+        // partial round costs half a round (up to one workgroup per CU) or a whole one; on its own it costs w / 16.
+        // N = 10 M (76.29 rounds) pays half a round either way and stays one launch (18.61 against 18.66 ms).
+        const int64_t n_tail = n - n_main;
+        const int64_t w = ((n_tail + 31) / 32 + cus - 1) / cus;
+        const int wq = w <= 4 ? 4 : w <= 8 ? 8 : w <= 12 ? 12 : 16;
+        const double plain = n_tail * 2 <= per_round ? 0.5 : 1.0;
+        if (n_main > 0 && n_tail > 0 && plain - wq / 16.0 < 0.1)
+            return launch_assign_mfma_wpb<D, 8>(X, n, staged, k, labels, n_changed, state, s, bs);
+    }
     if (n_main > 0) {
         const int r = launch_assign_mfma_wpb<D, 8>(X, n_main, staged, k, labels, n_changed, state, s, bs);
         if (r != MTP_OK) return r;
