@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "modular-trajectory-prediction-toolkit_amd"))
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md, HBM3E peak (spec); ~6300 achievable
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md, HBM3E peak (spec); a read-only stream measures 6.5-7.2 TB/s (profiles/r03_hbm_read_probe.txt)
 TRAFFIC_SOURCE = "profiles/pmc_traffic.json (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
 
 

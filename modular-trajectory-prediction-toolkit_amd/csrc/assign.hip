@@ -136,8 +136,8 @@ static int launch_assign_mfma_wpb(const float *X, int64_t n, const float *staged
 // Workgroups of equal cost run in lockstep, and the hardware spreads a last, partial round of up to CUs
 // workgroups one per CU but puts anything beyond that two per CU on some CUs: the launch time moves in steps
 // of half a round (tools/assign_sweep.sh), and N = 1.25 M points (9.54 rounds on 256 CUs) pays for 10.0.
-// So a single run is issued as two launches on the stream: the whole rounds with the 8-wave workgroups, then
-// the remaining points with workgroups of w = ceil(remaining waves / CUs) waves, rounded up to 4, 8, 12 or 16
+// So a single run whose tail that shortens (see the rule in launch_assign_mfma) is issued as two launches on the
+// stream: the whole rounds with the 8-wave workgroups, then the remaining points with workgroups of w = ceil(remaining waves / CUs) waves, rounded up to 4, 8, 12 or 16
 // (16 = a whole CU's wave slots at this register budget) -- at most one workgroup per CU, so the tail costs
 // w / 16 of a round instead of 1/2 or 1.  At N = 1.25 M: 36 + 3 tile-times per SIMD instead of 36 + 4
 // (2.41 against 2.47 ms; the optimum for 32-point wave tiles, 38.15 rounded up).  The labels do not depend on the split

@@ -5,16 +5,21 @@
 // scale (N=73 568, K=200) seeding is >50 % of the CPU wall time.
 //
 // The host draws the random numbers (NumPy RandomState, same order as sklearn) and uploads them
-// once; everything else is enqueued without a host sync: per new centre two launches,
-//   k_kpp_select  (1 workgroup)  pick the best of the previous candidates (argmin of potentials),
+// once; everything else is enqueued without a host sync, for all restarts of a batch together: per new centre
+//   k_kpp_pot_blocks (MTP_POT_OPENBLAS, the default) the float32 potentials of the candidate rows that can still
+//                                win, in the addition order of NumPy + OpenBLAS (sgemv_t blocks of 4096 points;
+//                                k_kpp_pot_sdot for the first centre), so that rand = u * pot carries sklearn's bits
+//   k_kpp_select  (1 workgroup per restart)  pick the best of the previous candidates (argmin of potentials),
 //                                then locate the L new candidates: rand_l = u_l * pot,
 //                                searchsorted(cumsum(closest), rand_l) via block sums + one
 //                                in-block scan per candidate, clip to N-1; gather their rows
-//   k_kpp_dist    (N/1024 WGs)   d = fp32(max(0, (-2 x.y + |x|^2) + |y|^2)) in double for the L
+//   k_kpp_dist_mfma / k_kpp_dist_tile / k_kpp_dist   d = fp32(max(0, (-2 x.y + |x|^2) + |y|^2)) in double for the L
 //                                candidates (sklearn metrics/pairwise.py:391-442,582-653: float32
 //                                input is upcast, stored back as float32, clamped), min with the
-//                                closest-so-far, per-block double sums (the potentials)
-// np.cumsum / the BLAS sums are replaced by double tree sums: differences ~1e-16 relative.
+//                                closest-so-far, per-block double sums
+// np.cumsum (float64 in sklearn) is replaced by double block sums + an in-block scan: differences ~1e-16 relative.
+// With MTP_POT_F64 the potentials are double sums too (the seeds then differ from sklearn's in about one restart in
+// four at N ~ 7e4).
 #include <cstdlib>
 #include <cstring>
 
