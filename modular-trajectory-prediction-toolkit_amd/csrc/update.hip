@@ -3,6 +3,7 @@
 //   k_accumulate      segmented sum of member rows by label -> double sums / counts
 //                     (sklearn cluster/_k_means_lloyd.pyx:215-218,143-152; get_modality's gather,
 //                      PCCSNet/utils/utility.py:98-104).  HBM-bound: one pass over X.
+//   k_accumulate_chain  the same sums as float32 chains in row order (MTP_LLOYD_SUMS_SKLEARN_1T: sklearn on one thread)
 //   k_mstep_centers   average, centre shift, staged image + ||c||^2 of the new centres
 //   k_mstep_flags     convergence decision (sklearn cluster/_kmeans.py:715-734)
 //   k_inertia         sklearn cluster/_k_means_common.pyx:94-124
