@@ -115,6 +115,23 @@ void launch_split(const float *X, int64_t n, const float *staged, int k, int32_t
     else launch_tail<D, 16>(Xt, n_tail, staged, k, lt, s);
 }
 
+// the direct (no-LDS) variant: its image is made from the staged one on first use
+static float *g_direct = nullptr;
+template <int D, int WPB, int PF, bool EPI = true>
+void launch_direct(const float *X, int64_t n, const float *staged, int k, int32_t *labels, hipStream_t s) {
+    const int tiles = mtp_n_tiles(k);
+    if (g_direct == nullptr) {
+        CK(hipMalloc(&g_direct, (size_t)tiles * mtp_direct_tile_f4<D>() * 16));
+        hipLaunchKernelGGL(k_direct_image<D>, dim3(tiles), dim3(256), 0, s, staged, g_direct);
+        CK(hipGetLastError());
+        CK(hipDeviceSynchronize());
+    }
+    const int64_t ppb = WPB * 32;
+    hipLaunchKernelGGL((k_assign_mfma_direct<D, WPB, PF, EPI>), dim3((unsigned)((n + ppb - 1) / ppb)), dim3(64 * WPB), 0, s, X, n,
+                       g_direct, (k + 31) / 32, labels);
+    CK(hipGetLastError());
+}
+
 static unsigned *g_tickets = nullptr;
 // SMALL: small units per workgroup at the end of the queue (-1: everything in small units)
 template <int D, int WPS, int SMALL>
@@ -195,6 +212,10 @@ int run(int64_t n, int k, const char *filter, int batch) {
         {"PT1 CTW2 WPB8 WPS4 no-epi", launch_v<D, 1, 2, 8, 4, false>, false},
         {"PT1 CTW1 WPB4 WPS4", launch_v<D, 1, 1, 4, 4, true>, true},
         {"PT1 CTW2 WPB16 WPS4", launch_v<D, 1, 2, 16, 4, true>, true},
+        {"DIRECT WPB4 PF2", launch_direct<D, 4, 2>, true},
+        {"DIRECT WPB4 PF4", launch_direct<D, 4, 4>, true},
+        {"DIRECT WPB8 PF4", launch_direct<D, 8, 4>, true},
+        {"DIRECT WPB4 PF4 no-epi", launch_direct<D, 4, 4, false>, false},
     };
     if (filter != nullptr) {  // keep the variants whose name contains it (the product variant always stays)
         std::vector<Variant> keep;

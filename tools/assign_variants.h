@@ -423,3 +423,125 @@ __global__ __launch_bounds__(512, WPS) void k_assign_mfma_queue(const float *__r
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// "Direct" variant: no LDS, no barriers, no LDS-DMA.  The centroid operands come straight from global memory
+// (L1 / L2: the image is 0.5 MB and every wave of the chip walks it front to back) with plain 16-byte loads, PF
+// u-steps ahead of the MFMAs that use them; the image is laid out so that a wave's load is one contiguous KB:
+//   tile t, u-step u, lane l  ->  float4 at ((t * (8 D + 8)) + u * 64 + l),   then the tile's 32 ||c||^2.
+// The waves of a workgroup are independent (the workgroup only exists to share a launch).  Same arithmetic in the
+// same order per (point, centroid) as k_assign_mfma: same labels.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__host__ __device__ constexpr int mtp_direct_tile_f4() { return 8 * D + 8; }  // float4 per tile: 32*D/4 operands + 32/4 norms
+
+// staged image (mtp_internal.h layout) -> direct layout; one block per tile
+template <int D>
+__global__ __launch_bounds__(256) void k_direct_image(const float *__restrict__ staged, float *__restrict__ out) {
+    constexpr int R = D / 4, U = D / 8, TILE_F = 32 * (D + 4) + 32;
+    const float4 *src = reinterpret_cast<const float4 *>(staged + (size_t)blockIdx.x * TILE_F);
+    float4 *dst = reinterpret_cast<float4 *>(out) + (size_t)blockIdx.x * mtp_direct_tile_f4<D>();
+    for (int e = threadIdx.x; e < U * 64; e += blockDim.x) {
+        const int u = e >> 6, l = e & 63, j = l & 31, h = l >> 5;
+        dst[e] = src[j * (R + 1) + 2 * u + h];
+    }
+    const float *c2 = staged + (size_t)blockIdx.x * TILE_F + 32 * (D + 4);
+    float *c2o = reinterpret_cast<float *>(dst + U * 64);
+    for (int e = threadIdx.x; e < 32; e += blockDim.x) c2o[e] = c2[e];
+}
+
+template <int D, int WPB, int PF, bool EPI = true>
+__global__ __launch_bounds__(64 * WPB, 4) void k_assign_mfma_direct(const float *__restrict__ X, int64_t n,
+                                                                   const float *__restrict__ img, int n_tiles,
+                                                                   int32_t *__restrict__ labels) {
+    constexpr int U = D / 8;
+    static_assert(U % PF == 0, "the operand ring must divide the u-steps of a tile");
+    constexpr int TQ = mtp_direct_tile_f4<D>();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t pbase = ((int64_t)blockIdx.x * WPB + wave) * 32;
+    const float4 *img4 = reinterpret_cast<const float4 *>(img);  // uniform base; lanes add their own 16 bytes
+
+    // the first PF operand quads travel while the points are fetched
+    float4 a[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) a[q] = img4[q * 64 + lane];
+
+    constexpr int SLOTS = D / 8;
+    constexpr int SG = SLOTS <= 12 ? SLOTS : 8;
+    float xr[D / 2];
+    {
+        int64_t row = pbase + j;
+        if (row >= n) row = n - 1;
+        const float4 *xp = reinterpret_cast<const float4 *>(X + row * D);
+#pragma unroll
+        for (int m0 = 0; m0 < SLOTS; m0 += SG) {
+            float4 v[SG];
+#pragma unroll
+            for (int g = 0; g < SG; ++g) v[g] = xp[2 * (m0 + g) + h];
+#pragma unroll
+            for (int g = 0; g < SG; ++g) {
+                const int m = m0 + g;
+                const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g].x), __float_as_uint(v[g].y), false, false);
+                const auto zw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g].z), __float_as_uint(v[g].w), false, false);
+                xr[4 * m + 0] = __uint_as_float(xy[0]);
+                xr[4 * m + 1] = __uint_as_float(zw[0]);
+                xr[4 * m + 2] = __uint_as_float(xy[1]);
+                xr[4 * m + 3] = __uint_as_float(zw[1]);
+            }
+        }
+    }
+
+    float best = __builtin_inff();
+    int breg = 0, btile = 0;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const float4 *tp = img4 + (size_t)tile * TQ;           // uniform
+        const int nt = tile + 1 < n_tiles ? tile + 1 : tile;  // beyond the last tile: a harmless re-read
+        const float4 *np = img4 + (size_t)nt * TQ;
+        float4 c2v[4];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4 cur = a[u % PF];
+            __builtin_amdgcn_sched_barrier(0);
+            a[u % PF] = (u + PF < U) ? tp[(u + PF) * 64 + lane] : np[(u + PF - U) * 64 + lane];
+            if (EPI && u == U - 2) {
+                // this tile's norms, two u-steps before the epilogue (lane half h needs rows 8 g + 4 h .. + 3 of quad g)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) c2v[g] = tp[U * 64 + 2 * g + h];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.x, xr[4 * u + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.y, xr[4 * u + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.z, xr[4 * u + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.w, xr[4 * u + 3], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!EPI) {
+            keep_alive(acc);
+            continue;
+        }
+        const float before = best;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float c2a[4] = {c2v[g].x, c2v[g].y, c2v[g].z, c2v[g].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dist = fmaf(-2.0f, acc[4 * g + r], c2a[r]);
+                const bool lt = dist < best;
+                best = lt ? dist : best;
+                breg = lt ? (4 * g + r) : breg;
+            }
+        }
+        btile = (best < before) ? tile : btile;
+    }
+    const int mine = btile * 32 + (breg & 3) + 8 * (breg >> 2) + 4 * h;
+    const float ob = __shfl_xor(best, 32);
+    const int oi = __shfl_xor(mine, 32);
+    const bool take = (ob < best) || (ob == best && oi < mine);
+    const int64_t row = pbase + j;
+    if (h == 0 && row < n) labels[row] = take ? oi : mine;
+}
