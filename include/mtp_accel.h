@@ -179,7 +179,8 @@ int mtp_pairwise_sumsq_f32(const float *v, int n, float *out, void *stream);
 
 /* Empty-cluster relocation, sklearn cluster/_k_means_common.pyx:167-211.
  * mtp_far_points_f32: the m points farthest from their assigned (old) centre, by
- * descending ||x - c||^2 (float, direct form), ties to the lowest index:
+ * descending distances = ((X - centers_old[labels]) ** 2).sum(axis=1) (:183; float32, NumPy's pairwise
+ * row sums bit for bit, so the SET of far points is sklearn's), ties to the lowest index:
  *   far_val[m] float, far_idx[m] int64 (row index + idx_offset), far_lab[m] int32,
  *   far_rows[m, d] float; entries beyond the number of points are (-1, -1, -1, 0...).
  *   dist_scratch: mtp_far_points_scratch_bytes(n) bytes (the n distances + the search's partial winners). */

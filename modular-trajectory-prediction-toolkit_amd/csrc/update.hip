@@ -345,6 +345,76 @@ __device__ inline float pairwise_sum_sq_numpy(const float *sh, int n) {
     return 0.0f + ret;  // np.add.reduce starts from the identity
 }
 
+// The same order over (a[i] - b[i])^2: one row of sklearn's `distances = ((X - centers_old[labels]) ** 2).sum(axis=1)`
+// (_k_means_common.pyx:183) -- float32 difference, float32 square, NumPy's pairwise sum along the row.
+__device__ inline float pw_leaf_sqdiff(const float *__restrict__ a, const float *__restrict__ b, int off, int n) {
+    if (n < 8) {
+        float res = -0.0f;
+        for (int i = 0; i < n; ++i) {
+            const float v = a[off + i] - b[off + i];
+            res += v * v;
+        }
+        return res;
+    }
+    float r[8];
+    for (int q = 0; q < 8; ++q) {
+        const float v = a[off + q] - b[off + q];
+        r[q] = v * v;
+    }
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int q = 0; q < 8; ++q) {
+            const float v = a[off + i + q] - b[off + i + q];
+            r[q] += v * v;
+        }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) {
+        const float v = a[off + i] - b[off + i];
+        res += v * v;
+    }
+    return res;
+}
+__device__ inline float pairwise_sum_sqdiff_numpy(const float *__restrict__ a, const float *__restrict__ b, int n) {
+    struct Frame {
+        int off, n, stage;
+        float left;
+    } st[40];
+    int sp = 0;
+    st[sp++] = Frame{0, n, 0, 0.f};
+    float ret = 0.f;
+    while (sp > 0) {
+        Frame &f = st[sp - 1];
+        if (f.n <= 128) {
+            ret = pw_leaf_sqdiff(a, b, f.off, f.n);
+            --sp;
+            continue;
+        }
+        int n2 = f.n / 2;
+        n2 -= n2 % 8;
+        if (f.stage == 0) {
+            f.stage = 1;
+            st[sp++] = Frame{f.off, n2, 0, 0.f};
+        } else if (f.stage == 1) {
+            f.left = ret;
+            f.stage = 2;
+            st[sp++] = Frame{f.off + n2, f.n - n2, 0, 0.f};
+        } else {
+            ret = f.left + ret;
+            --sp;
+        }
+    }
+    return 0.0f + ret;
+}
+
+// distances of the empty-cluster relocation: what sklearn ranks its far points on, bit for bit.  One thread per row
+// (relocations are rare: the kernel's speed does not show in a fit).
+__global__ __launch_bounds__(256) void k_far_distances(const float *__restrict__ X, int64_t n, int d,
+                                                       const float *__restrict__ C, const int32_t *__restrict__ labels,
+                                                       float *dist) {
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x)
+        dist[row] = pairwise_sum_sqdiff_numpy(X + row * d, C + (size_t)labels[row] * d, d);
+}
+
 __global__ void k_pairwise_sumsq(const float *v, int n, float *out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *out = pairwise_sum_sq_numpy(v, n);
 }
@@ -918,8 +988,16 @@ extern "C" int mtp_far_points_f32(const float *X, int64_t n, int d, const float 
     MTP_REQUIRE(X && C_old && labels && far_val && far_idx && far_lab && far_rows && dist_scratch && m > 0 && d > 0,
                 "mtp_far_points: bad arguments");
     hipStream_t s = mtp_stream(stream);
-    int rc = mtp_launch_inertia(X, n, d, C_old, labels, nullptr, dist_scratch, s);
-    if (rc != MTP_OK) return rc;
+    {
+        // sklearn's own `distances` (float32 row sums in NumPy's pairwise order): two points whose distances differ
+        // in the last bit rank as they do there.  (Until round 3 the ranking used the inertia kernel's per-point
+        // terms, groups of four added in double: a near-tie at the m-th place could pick the other point.)
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_far_distances, dim3((unsigned)blocks), dim3(256), 0, s, X, n, d, C_old, labels, dist_scratch);
+        MTP_LAUNCH_CHECK();
+    }
     // m argmax passes, each a grid-wide scan (<= 1024 slices) + a one-block merge; the slice winners
     // live behind the n distances in the caller's scratch (mtp_far_points_scratch_bytes), so searches
     // on different streams do not share anything

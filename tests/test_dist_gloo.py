@@ -88,7 +88,7 @@ class NumpyOps:
         lab = torch.full((m,), -1, dtype=torch.int32)
         rows = torch.zeros((m, d), dtype=torch.float32)
         if n:
-            _, pp = O.inertia(X.numpy(), C_old.numpy(), labels.numpy(), return_per_point=True)
+            pp = ((X.numpy() - C_old.numpy()[labels.numpy()]) ** 2).sum(axis=1)  # sklearn's `distances`, NumPy's order
             order = np.lexsort((np.arange(n), -pp))[:m]
             for q, i in enumerate(order):
                 val[q], idx[q], lab[q] = float(pp[i]), int(i) + idx_offset, int(labels[i])

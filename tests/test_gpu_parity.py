@@ -327,6 +327,54 @@ def test_relocation_serves_only_the_originally_empty_clusters(gpu_device):
     assert out[k * d:k * d + k].tolist() == [1, 1, 0, 4] and not np.signbit(out[k * d:k * d + k]).any()
 
 
+@pytest.mark.parametrize("d", [12, 64, 128, 300])
+def test_far_points_rank_on_numpys_row_sums(d, gpu_device):
+    """sklearn picks its far points by `distances = ((X - centers_old[labels]) ** 2).sum(axis=1)`
+    (_k_means_common.pyx:183-187): float32 differences and squares, NumPy's pairwise sum along the row.  The search
+    ranks on exactly those bits (descending, ties to the lowest index), so two points whose distances differ in the
+    last bit rank as they do in sklearn."""
+    from pccs_accel._lib import check, lib, ptr, stream_ptr
+    n, k, m = 3000, 17, 40
+    X = datagen.make_encodings(300 + d, n, d, 9, 1500, 700)
+    X[1500] = X[7]        # exact ties between rows far apart
+    X[2999] = X[8]
+    C = X[datagen.make_init_indices(3, n, k)].copy()
+    labels = O.assign(X, C, backend="chain")
+    want_d = ((X - C[labels]) ** 2).sum(axis=1)
+    order = np.lexsort((np.arange(n), -want_d))[:m]
+    Xd, Cd, ld = dev(X, gpu_device), dev(C, gpu_device), dev(labels, gpu_device)
+    val = torch.empty(m, dtype=torch.float32, device=gpu_device)
+    idx = torch.empty(m, dtype=torch.int64, device=gpu_device)
+    lab = torch.empty(m, dtype=torch.int32, device=gpu_device)
+    rows = torch.empty((m, d), dtype=torch.float32, device=gpu_device)
+    scratch = torch.empty(int(lib().mtp_far_points_scratch_bytes(n)), dtype=torch.uint8, device=gpu_device)
+    check(lib().mtp_far_points_f32(ptr(Xd), n, d, ptr(Cd), ptr(ld), m, 0, ptr(val), ptr(idx), ptr(lab), ptr(rows),
+                                   ptr(scratch), stream_ptr()), "mtp_far_points_f32")
+    assert np.array_equal(idx.cpu().numpy(), order)
+    assert np.array_equal(val.cpu().numpy(), want_d[order])          # the distances themselves, bit for bit
+    assert np.array_equal(lab.cpu().numpy(), labels[order]) and np.array_equal(rows.cpu().numpy(), X[order])
+
+
+def test_relocation_with_a_near_tie_at_the_last_far_point(gpu_device):
+    """Found by tests/fuzz_gpu_parity.py (seed 6, round 31): 23 of 39 clusters start empty and the 23rd and 24th
+    farthest points are 2e-6 apart -- closer than the difference between two float summation orders of the same
+    distance.  With the ranking on NumPy's own row sums the run equals the oracle's again."""
+    from pccs_accel import kernels as K
+    rs = np.random.RandomState(1143311898)
+    n, d, k = int(rs.randint(60, 2500)), int(rs.choice([64, 96, 128, 12])), int(rs.randint(3, 40))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    X = X - X.mean(0)
+    C0 = X[rs.choice(n, size=k, replace=False)].copy()
+    n_far = int(rs.randint(1, k))
+    C0[rs.choice(k, size=n_far, replace=False)] += np.float32(50.0)
+    assert (n, d, k, n_far) == (535, 128, 39, 23)
+    tol = float(O.tolerance(X))
+    labels, inertia, centers, n_iter = K.lloyd(dev(X, gpu_device), dev(C0, gpu_device), max_iter=40, tol_abs=tol, check_every=4)
+    ol, oi, oc, on = O.kmeans_single_lloyd(X, C0, 40, tol, sums="f64", far_order="descending")
+    assert n_iter == on and np.array_equal(labels.cpu().numpy(), ol)
+    assert np.allclose(centers.cpu().numpy(), oc, rtol=RTOL, atol=1e-6) and np.isclose(inertia, oi, rtol=RTOL)
+
+
 # ------------------------------------------------------------------------------------------
 # ADE / FDE and best-of-K
 # ------------------------------------------------------------------------------------------

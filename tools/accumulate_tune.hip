@@ -75,10 +75,12 @@ int main(int argc, char **argv) {
     k_labels<<<4096, 256>>>(labels, n, k, 5);
     CK(hipDeviceSynchronize());
     const Cfg big = {152 * 1024, 1024, 256}, half = {76 * 1024, 1024, 512}, half512 = {76 * 1024, 512, 512};
+    const Cfg r8 = {132 * 1024, 1024, 256};  // K = 1024, D = 128: 8 cluster ranges of 128 x 32 row chunks = 256 workgroups
     std::vector<Variant> vs = {
         {"f64 G4 1024thr 152KB (product)", launch_v<32, 4, double, true>, big, true},
         {"f64 G4 d=128 const", launch_v<32, 4, double, true, 128>, big, true},
         {"f64 G4 d=128 const, nt rows", launch_v<32, 4, double, true, 128, true>, big, true},
+        {"f64 G4 d=128 nt, 8 ranges x 32", launch_v<32, 4, double, true, 128, true>, r8, true},
         {"f64 G8 d=128 const, nt rows", launch_v<32, 8, double, true, 128, true>, big, true},
         {"f64 G4 no-add d=128 nt (load only)", launch_v<32, 4, double, false, 128, true>, big, false},
         {"f64 G8 1024thr 152KB", launch_v<32, 8, double, true>, big, true},
