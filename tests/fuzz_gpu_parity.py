@@ -24,6 +24,7 @@ import glue_oracle as G  # noqa: E402
 import kmeans_oracle as O  # noqa: E402
 from pccs_accel import kernels as K  # noqa: E402
 from pccs_accel import seeding  # noqa: E402
+from pccs_accel import clustering, scene  # noqa: E402
 
 DEV = torch.device("cuda:0")
 FAIL = []
@@ -257,9 +258,84 @@ def case_large(rs):
     check(ok_in, "large.batched.inertia", **info)
 
 
+def case_fit(rs):
+    """Whole seeded fits: column statistics in NumPy's order, k-means++ x n_init, Lloyd, sklearn's restart rule."""
+    n, d = int(rs.randint(60, 3000)), int(rs.choice([64, 96, 128, 20]))
+    k = int(rs.randint(1, min(n, 24) + 1))
+    n_init = int(rs.randint(1, 5))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k), 1500, 700)
+    seed = int(rs.randint(1 << 30))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fit = clustering.kmeans_fit(dev(X), k, n_init=n_init, random_state=seed, sums="sklearn_1t")
+        ofit = O.kmeans_fit(X, k, n_init=n_init, random_state=seed)  # sklearn on one thread (float32 sums in row order)
+    info = dict(n=n, d=d, k=k, n_init=n_init, seed=seed)
+    check(fit["n_iter"] == ofit["n_iter"], "fit.n_iter", got=fit["n_iter"], want=ofit["n_iter"], **info)
+    check(np.array_equal(fit["labels"].cpu().numpy(), ofit["labels"]), "fit.labels", **info)
+    check(np.allclose(fit["centers"].cpu().numpy(), ofit["centers"], rtol=1e-6, atol=1e-6), "fit.centers", **info)
+    check(np.isclose(fit["inertia"], ofit["inertia"], rtol=1e-5), "fit.inertia", **info)
+    # column statistics: NumPy's own bits
+    tol_abs, mean32 = clustering.tolerance_and_mean(dev(X), 1e-4)
+    check(np.array_equal(mean32.cpu().numpy(), X.mean(axis=0)), "fit.mean_bits", **info)
+    check(tol_abs == float(np.mean(np.var(X, axis=0)) * 1e-4), "fit.tol_bits", **info)
+
+
+def case_scene(rs):
+    """Scene neighbour lists and soft labels against the restated process_scene / gen_prob."""
+    sizes = [int(rs.randint(1, 120)) for _ in range(int(rs.randint(1, 5)))]
+    n = sum(sizes)
+    trj = np.concatenate([datagen.make_scene_trajectories(int(rs.randint(1 << 30)), sz) for sz in sizes])
+    marks = np.concatenate([[0], np.cumsum(sizes)])
+    obs_len = int(rs.choice([8, 2, 20]))
+    rad = float(rs.choice([0.5, 1.0, 2.0, 6.0]))
+    offsets, ids = scene.scene_neighbors(trj, marks, obs_len, rad)
+    want = G.process_scene(trj, marks, obs_len, rad)
+    off_h, ids_h = offsets.cpu().numpy(), ids.cpu().numpy()
+    ok = all(ids_h[off_h[i]:off_h[i + 1]].tolist() == want[i] for i in range(n))
+    info = dict(n=n, scenes=len(sizes), obs_len=obs_len, rad=rad)
+    check(ok, "scene.neighbours", **info)
+    k = int(rs.randint(1, 40))
+    labels = rs.randint(0, k, size=n).astype(np.int32)
+    dense = scene.soft_labels(offsets, ids, labels, k).cpu().numpy()
+    rc, rp = G.gen_prob(want, labels)
+    check(np.array_equal(dense, G.scene_soft_labels(rc, rp, k)), "scene.soft_labels", k=k, **info)
+
+
+def case_reranked(rs):
+    n, m, t = int(rs.randint(1, 300)), int(rs.randint(2, 80)), 12
+    dt = np.float64 if rs.rand() < 0.5 else np.float32
+    pred, gt, _ = datagen.make_candidate_sets(int(rs.randint(1 << 30)), n, m, t, dtype=dt)
+    keep = int(rs.randint(1, m + 1))
+    order = np.stack([rs.permutation(m)[:keep] for _ in range(n)]).astype(np.int32)
+    best_of = int(rs.randint(1, keep + 1))
+    mode = int(rs.randint(0, 3))
+    g = K.best_of_k_reranked(dev(pred), dev(gt), dev(order), mode=mode, best_of=best_of)
+    re = np.take_along_axis(pred, order[:, :, None, None].astype(np.int64), axis=1)
+    o = O.best_of_k(np.ascontiguousarray(re), gt, mode=mode, best_of=best_of)
+    info = dict(n=n, m=m, keep=keep, best_of=best_of, mode=mode, dt=dt.__name__)
+    check(np.array_equal(g["idx"].cpu().numpy(), o["idx"]), "reranked.idx", **info)
+    check(np.allclose(g["min_ade"].cpu().numpy(), o["min_ade"], rtol=1e-5, atol=0), "reranked.min_ade", **info)
+    check(np.allclose(g["min_fde"].cpu().numpy(), o["min_fde"], rtol=1e-5, atol=0), "reranked.min_fde", **info)
+
+
+def case_seeding_big_k(rs):
+    """More local trials (L = 2 + ln k: 8 from k = 404, 9 from k = 1097: beyond the 8-row candidate tile)."""
+    k = int(rs.choice([410, 700, 1100, 1250]))
+    n, d = int(rs.randint(k + 10, 4000)), int(rs.choice([64, 96, 128, 20]))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, 40, 1500, 700)
+    X = X - X.mean(0)
+    seed = int(rs.randint(1 << 30))
+    _, idx = seeding.kmeans_plusplus(dev(X), k, np.random.RandomState(seed))
+    _, widx = O.kmeans_plusplus(X, k, np.random.RandomState(seed))
+    got = idx.cpu().numpy()
+    check(np.array_equal(got, widx), "seeding_big_k.indices", n=n, d=d, k=k, seed=seed,
+          first_diff=int(np.argmax(got != widx)) if (got != widx).any() else -1)
+
+
 CASES = [case_assign, case_sums, case_lloyd, case_best_of_k, case_decode, case_nms, case_relocation, case_seeding,
-         case_one_thread_mode, case_targets]
-RARE = [case_large]  # every tenth round
+         case_one_thread_mode, case_targets, case_fit, case_scene, case_reranked]
+RARE = [case_large, case_seeding_big_k]  # every tenth round
 
 
 def main():
