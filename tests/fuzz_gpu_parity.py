@@ -3,6 +3,7 @@
 for a bounded time.  Development aid, run on the MI355X box:
 
     python tests/fuzz_gpu_parity.py [seconds] [seed]
+    python tests/fuzz_gpu_parity.py replay <case function> <sub-seed> [<sub-seed> ...]
 
 Not collected by pytest (the fixed-shape tests in tests/test_gpu_*.py are the suite); lives under tests/ because it
 imports the oracle, which is test infrastructure only.  Same bars as the suite: integer outputs bit-exact, sums to
@@ -269,7 +270,9 @@ def case_fit(rs):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         fit = clustering.kmeans_fit(dev(X), k, n_init=n_init, random_state=seed, sums="sklearn_1t")
-        ofit = O.kmeans_fit(X, k, n_init=n_init, random_state=seed)  # sklearn on one thread (float32 sums in row order)
+        # sklearn on one thread: float32 sums in row order, float32 inertia chain (its order decides the restart rule
+        # when two restarts end within a rounding error of each other)
+        ofit = O.kmeans_fit(X, k, n_init=n_init, random_state=seed, sums="f32", inertia_order="f32_chain", far_order="descending")
     info = dict(n=n, d=d, k=k, n_init=n_init, seed=seed)
     check(fit["n_iter"] == ofit["n_iter"], "fit.n_iter", got=fit["n_iter"], want=ofit["n_iter"], **info)
     check(np.array_equal(fit["labels"].cpu().numpy(), ofit["labels"]), "fit.labels", **info)
@@ -338,7 +341,20 @@ CASES = [case_assign, case_sums, case_lloyd, case_best_of_k, case_decode, case_n
 RARE = [case_large, case_seeding_big_k]  # every tenth round
 
 
+def replay(case_name, sub_seeds):
+    """python tests/fuzz_gpu_parity.py replay <case function> <sub-seed> [...]: one case again from the seed of its own
+    RandomState (a failing case's seed is found by walking the main stream on the CPU: the draws do not depend on
+    the GPU's results)."""
+    fn = globals()[case_name]
+    for sub in sub_seeds:
+        fn(np.random.RandomState(int(sub)))
+    print(f"replay {case_name}: {sum(COUNT.values())} checks, {len(FAIL)} failures")
+    sys.exit(1 if FAIL else 0)
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[1] == "replay":
+        replay(sys.argv[2], sys.argv[3:])
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rs = np.random.RandomState(seed)
