@@ -13,9 +13,10 @@
 // Arithmetic follows the reference's dtypes: positions are float32 (main.py:81 `.float()`), their
 // difference and np.linalg.norm (dx*dx + dy*dy, sqrt; rounded separately, -ffp-contract=off) stay
 // float32 and are compared with float32(rad) (NumPy 2 weak-scalar promotion); speed, angle and all
-// their comparisons are double.  hypot / atan2 come from the device math library, which may
-// differ from glibc's in the last bit: a neighbour can flip only if a speed ratio or heading
-// difference sits within ~1e-15 relative of its threshold (tests classify any mismatch that way).
+// their comparisons are double.  The speed is glibc's hypot restated (hypot_glibc below: the reference's bits on a
+// glibc >= 2.35 host); atan2 comes from the device math library, which may differ from glibc's in the last bit:
+// a neighbour can flip only if a heading difference sits within ~1e-15 relative of 0.1 pi (tests classify any
+// mismatch that way).
 //
 // One 64-lane wave per sample, lanes over the candidates j of its scene (their 24 bytes come from
 // L2: a scene's attributes are a few hundred KB).  The neighbour lists are produced as CSR in two
@@ -24,6 +25,46 @@
 #include <cmath>
 
 #include "mtp_internal.h"
+
+// hypot(x, y) as glibc >= 2.35 computes it on x86-64 (sysdeps/ieee754/dbl-64/e_hypot.c, the build without
+// __FP_FAST_FMA): sqrt(ax^2 + ay^2) followed by one correction step in plain double arithmetic -- every operation
+// correctly rounded and none contracted (-ffp-contract=off), so the speed carries the bits of the reference's
+// cmath.polar(...)[0] (Python hands the modulus to libm's hypot).  Established against cmath.polar itself on 3e5
+// float32-valued pairs (0 mismatches); the device library's own hypot differs in the last bit about once in 20, which is
+// enough to move a neighbour across `0.9 s_i < s_j < 1.1 s_i` when the ratio sits on the boundary (found by
+// tests/fuzz_gpu_parity.py).  An older glibc (fdlibm's hypot) may differ from this in the last bit: unpinned there.
+__device__ inline double hypot_glibc(double x, double y) {
+    if (!(isfinite(x) && isfinite(y))) return (isinf(x) || isinf(y)) ? (double)__builtin_inf() : x + y;
+    x = fabs(x);
+    y = fabs(y);
+    double ax = x < y ? y : x, ay = x < y ? x : y;
+    constexpr double SCALE = 0x1p-600, LARGE_VAL = 0x1p+511, TINY_VAL = 0x1p-459, EPS = 0x1p-54;
+    auto kernel = [](double ax, double ay) -> double {
+        double h = sqrt(ax * ax + ay * ay);
+        double t1, t2;
+        if (h <= 2.0 * ay) {
+            const double delta = h - ay;
+            t1 = ax * (2.0 * delta - ax);
+            t2 = (delta - 2.0 * (ax - ay)) * delta;
+        } else {
+            const double delta = h - ax;
+            t1 = 2.0 * delta * (ax - 2.0 * ay);
+            t2 = (4.0 * delta - ay) * ay + delta * delta;
+        }
+        h -= (t1 + t2) / (2.0 * h);
+        return h;
+    };
+    if (ax > LARGE_VAL) {
+        if (ay <= ax * EPS) return ax + ay;
+        return kernel(ax * SCALE, ay * SCALE) / SCALE;
+    }
+    if (ay < TINY_VAL) {
+        if (ax >= TINY_VAL / EPS || ax == 0.0) return ax + ay;
+        return kernel(ax / SCALE, ay / SCALE) * SCALE;
+    }
+    if (ay <= ax * EPS) return ax + ay;
+    return kernel(ax, ay);
+}
 
 __global__ __launch_bounds__(256) void k_speed_angle(const float *__restrict__ trj, int64_t n, int tlen, int t,
                                                      float *__restrict__ last, double *__restrict__ sa) {
@@ -35,7 +76,7 @@ __global__ __launch_bounds__(256) void k_speed_angle(const float *__restrict__ t
     const double dx = (double)dxf, dy = (double)dyf;
     last[2 * i] = xt;
     last[2 * i + 1] = yt;
-    sa[2 * i] = hypot(dx, dy);
+    sa[2 * i] = hypot_glibc(dx, dy);
     sa[2 * i + 1] = atan2(dy, dx);
 }
 

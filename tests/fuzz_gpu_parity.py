@@ -336,8 +336,79 @@ def case_seeding_big_k(rs):
           first_diff=int(np.argmax(got != widx)) if (got != widx).any() else -1)
 
 
+def case_fit_default(rs):
+    """The default mode (double sums) restart by restart against the oracle's same variant: seeds, n_iter, labels."""
+    n, d = int(rs.randint(60, 2500)), int(rs.choice([64, 96, 128, 20]))
+    k = int(rs.randint(1, min(n, 24) + 1))
+    n_init = int(rs.randint(1, 4))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k), 1500, 700)
+    seed = int(rs.randint(1 << 30))
+    import warnings
+    restarts = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clustering.kmeans_fit(dev(X), k, n_init=n_init, random_state=seed, restarts_out=restarts)
+    Xc = X - X.mean(axis=0)
+    tol = float(O.tolerance(X))
+    r2 = np.random.RandomState(seed)
+    info = dict(n=n, d=d, k=k, n_init=n_init, seed=seed)
+    for b in range(n_init):
+        c0, idx = O.kmeans_plusplus(Xc, k, r2)
+        ol, oi, oc, on = O.kmeans_single_lloyd(Xc, c0, 300, tol, sums="f64", far_order="descending")
+        check(np.array_equal(restarts[b]["indices"].cpu().numpy(), idx), "fit_default.seeds", restart=b, **info)
+        check(restarts[b]["n_iter"] == on, "fit_default.n_iter", restart=b, got=restarts[b]["n_iter"], want=on, **info)
+        check(np.array_equal(restarts[b]["labels"].cpu().numpy(), ol), "fit_default.labels", restart=b, **info)
+        check(np.isclose(restarts[b]["inertia"], oi, rtol=1e-6), "fit_default.inertia", restart=b, **info)
+
+
+def case_dropins(rs):
+    """The reference-named entry points on small inputs: metrics.py, get_modality, cluster_data with np.random.seed."""
+    from pccs_accel.utils.metrics import displacement_error, final_displacement_error
+    from pccs_accel.utils.utility import cluster_data, get_modality
+    b, t = int(rs.randint(1, 40)), int(rs.choice([12, 8, 1]))
+    pred, gt = datagen.make_trajectories(int(rs.randint(1 << 30)), 1, b, t)
+    p, g = torch.from_numpy(pred[0]), torch.from_numpy(gt)           # [b, t, 2], [1, t, 2] like train_steps.py:219-220
+    ade = displacement_error(p.to(DEV), g.to(DEV)).cpu().numpy()
+    fde = final_displacement_error(p[:, -1].to(DEV), g[:, -1].to(DEV)).cpu().numpy()
+    check(np.allclose(ade, O.displacement_error(pred[0], gt), rtol=1e-6, atol=0), "dropin.displacement_error", b=b, t=t)
+    check(np.allclose(fde, O.final_displacement_error(pred[0][:, -1], gt[:, -1]), rtol=1e-6, atol=0), "dropin.final_displacement_error", b=b, t=t)
+    n, d, k = int(rs.randint(30, 400)), int(rs.choice([96, 64, 20])), int(rs.randint(1, 7))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k), 1500, 700)
+    labels = rs.randint(0, k, size=n).astype(np.int32)
+    labels[:k] = np.arange(k)                                         # no empty cluster (KeyError otherwise, tested elsewhere)
+    mod = get_modality(torch.from_numpy(X), labels, k).numpy()
+    check(np.allclose(mod, O.get_modality(X, labels, k), rtol=1e-6, atol=1e-7), "dropin.get_modality", n=n, d=d, k=k)
+    seed = int(rs.randint(1 << 30))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(seed)
+        try:
+            got = cluster_data(X.copy(), k)
+        except KeyError as e:
+            got = ("KeyError", e.args)
+        np.random.seed(seed)
+        try:
+            want = O.cluster_data(X.copy(), k)
+        except KeyError as e:
+            want = ("KeyError", e.args)
+    if isinstance(want, tuple) and want and isinstance(want[0], str) or isinstance(got, tuple) and got and isinstance(got[0], str):
+        check(got == want, "dropin.cluster_data.keyerror", n=n, d=d, k=k, seed=seed)
+    else:
+        # the reference's sums are float32 (and 8-threaded), the default mode's double: the same labels, or -- where two
+        # restarts end within a rounding error of each other -- another restart's labelling of equal quality
+        def quality(lab):
+            c = O.get_modality(X, lab, k)
+            return float(((X.astype(np.float64) - c[lab]) ** 2).sum())
+        same = np.array_equal(got[0], want[0])
+        check(same or np.isclose(quality(got[0]), quality(want[0]), rtol=1e-4), "dropin.cluster_data.labels",
+              mism=int((got[0] != want[0]).sum()), n=n, d=d, k=k, seed=seed)
+        check(np.array_equal(got[1], np.bincount(got[0], minlength=k)), "dropin.cluster_data.sizes", n=n, k=k)
+        check(got[0].dtype == np.int32 and got[1].dtype == np.int64 and int(got[1].sum()) == n, "dropin.cluster_data.dtypes", n=n, k=k)
+
+
 CASES = [case_assign, case_sums, case_lloyd, case_best_of_k, case_decode, case_nms, case_relocation, case_seeding,
-         case_one_thread_mode, case_targets, case_fit, case_scene, case_reranked]
+         case_one_thread_mode, case_targets, case_fit, case_scene, case_reranked, case_fit_default, case_dropins]
 RARE = [case_large, case_seeding_big_k]  # every tenth round
 
 

@@ -326,6 +326,35 @@ def test_scene_neighbours_shapes_vs_oracle(sizes, rad, gpu_device):
         scene.soft_labels(offsets, ids, labels, 36 if labels.max() == 36 else int(labels.max()))
 
 
+def test_speed_carries_the_bits_of_cmath_polar(gpu_device):
+    """data_process.py:125-131: cmath.polar(complex(dx, dy)) -- the modulus is libm's hypot.  The kernel restates
+    glibc's (>= 2.35) hypot in plain double arithmetic, so the speeds are the reference's bit for bit (the device
+    library's own hypot differs in the last bit about once in 20, enough to move a neighbour whose speed ratio sits
+    on the 0.9 / 1.1 boundary: found by tests/fuzz_gpu_parity.py, seed 9); the angle comes from the device's atan2
+    and may differ from glibc's in the last bits (a heading difference within ~1e-15 relative of 0.1 pi)."""
+    import cmath
+    from pccs_accel._lib import check, lib, ptr, stream_ptr
+    rs = np.random.RandomState(5)
+    n = 40000
+    trj = np.zeros((n, 2, 2), dtype=np.float32)
+    scale = rs.choice([1e-3, 1.0, 30.0, 1e3], size=(n, 1)).astype(np.float32)
+    trj[:, 1] = rs.randn(n, 2).astype(np.float32) * scale
+    trj[: n // 3, 1] = np.round(trj[: n // 3, 1] * 4096) / 4096   # dyadic steps like the fixtures'
+    trj[:50, 1] = 0                                              # standing still
+    trj[50:100, 1, 0] = 0                                        # along an axis
+    trj[:, 0] = rs.randn(n, 2).astype(np.float32)
+    trj[:, 1] += trj[:, 0]
+    d_trj = torch.from_numpy(trj).to(gpu_device)
+    last = torch.empty((n, 2), dtype=torch.float32, device=gpu_device)
+    sa = torch.empty((n, 2), dtype=torch.float64, device=gpu_device)
+    check(lib().mtp_speed_angle_f32(ptr(d_trj), n, 2, 1, ptr(last), ptr(sa), stream_ptr()), "mtp_speed_angle_f32")
+    got = sa.cpu().numpy()
+    want = np.array([cmath.polar(complex(*(trj[i, 1] - trj[i, 0]))) for i in range(n)])
+    assert np.array_equal(got[:, 0], want[:, 0])                    # the speed: every bit
+    assert np.allclose(got[:, 1], want[:, 1], rtol=1e-15, atol=1e-15)
+    assert np.array_equal(last.cpu().numpy(), trj[:, 1])
+
+
 def test_index_inputs_are_validated_on_the_host(gpu_device):
     """Index arrays that a kernel dereferences are range-checked before the launch."""
     from pccs_accel import kernels as K
