@@ -153,8 +153,9 @@ def case_nms(rs):
     max_samples = int(rs.randint(1, m + 1))
     best_of = int(rs.randint(1, max_samples + 1))
     thresh = float(rs.choice([0.1, 0.3, 1.0]))
-    order, n_sel = K.nms_rerank(dev(pred), dev(scores), max_samples, best_of, 2, thresh)
-    worder, wsel, wout = G.nms_rerank(pred, scores, max_samples, best_of, 2, thresh)
+    bin_size = int(rs.choice([2, 1, 3, 5]))
+    order, n_sel = K.nms_rerank(dev(pred), dev(scores), max_samples, best_of, bin_size, thresh)
+    worder, wsel, wout = G.nms_rerank(pred, scores, max_samples, best_of, bin_size, thresh)
     info = dict(n=n, m=m, dt=dt.__name__, sdt=scores.dtype.name, max_samples=max_samples, best_of=best_of, thresh=thresh)
     check(np.array_equal(order.cpu().numpy(), worder), "nms_rerank.order", **info)
     check(np.array_equal(n_sel.cpu().numpy(), wsel), "nms_rerank.n_selected", **info)
@@ -180,6 +181,34 @@ def case_relocation(rs):
     check(np.isclose(inertia, oi, rtol=1e-5), "relocation.inertia", **info)
 
 
+def case_batched_relocation(rs):
+    """Restarts of one batch that pause for a relocation at different iterations, beside restarts that never do."""
+    n, d, k = int(rs.randint(200, 4000)), int(rs.choice([64, 96, 128])), int(rs.randint(3, 60))
+    b = int(rs.choice([2, 4, 7, 12]))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    X = X - X.mean(0)
+    tol = float(O.tolerance(X))
+    C0s = np.stack([X[rs.choice(n, size=k, replace=False)] for _ in range(b)])
+    for r in range(b):
+        if rs.rand() < 0.6:
+            C0s[r, rs.choice(k, size=int(rs.randint(1, k)), replace=False)] += np.float32(50.0)
+    ce = int(rs.choice([1, 4]))
+    bl, bi, bc, bn = K.lloyd_batched(dev(X), dev(C0s), max_iter=30, tol_abs=tol, check_every=ce)
+    bl, bi, bc = bl.cpu().numpy(), bi.cpu().numpy(), bc.cpu().numpy()
+    ok_iter = ok_lab = ok_c = ok_in = True
+    for r in range(b):
+        ol, oi, oc, on = O.kmeans_single_lloyd(X, C0s[r], 30, tol, sums="f64", far_order="descending")
+        ok_iter &= (bn[r] == on)
+        ok_lab &= bool(np.array_equal(bl[r], ol))
+        ok_c &= bool(np.allclose(bc[r], oc, rtol=1e-5, atol=1e-6))
+        ok_in &= bool(np.isclose(bi[r], oi, rtol=1e-6))
+    info = dict(n=n, d=d, k=k, restarts=b, check_every=ce)
+    check(ok_iter, "batched_relocation.n_iter", got=bn, **info)
+    check(ok_lab, "batched_relocation.labels", **info)
+    check(ok_c, "batched_relocation.centers", **info)
+    check(ok_in, "batched_relocation.inertia", **info)
+
+
 def case_seeding(rs):
     n, d = int(rs.randint(50, 9000)), int(rs.choice([64, 96, 128, 12, 20, 32]))
     k = int(rs.randint(1, min(n, 48) + 1))
@@ -193,10 +222,11 @@ def case_seeding(rs):
     check(np.array_equal(got, widx), "seeding.indices", first_diff=int(np.argmax(got != widx)) if (got != widx).any() else -1, **info)
     # three restarts in shared launches == one at a time, from the same stream of draws
     r1, r2 = np.random.RandomState(seed), np.random.RandomState(seed)
-    draws = [seeding.draw(r1, n, k) for _ in range(3)]
+    nb = int(rs.choice([2, 3, 5, 20]))
+    draws = [seeding.draw(r1, n, k) for _ in range(nb)]
     _, bidx = seeding.kmeans_plusplus_batched(dev(X), k, draws)
-    singles = [seeding.kmeans_plusplus(dev(X), k, r2)[1] for _ in range(3)]
-    check(all(torch.equal(bidx[i], singles[i]) for i in range(3)), "seeding.batched", **info)
+    singles = [seeding.kmeans_plusplus(dev(X), k, r2)[1] for _ in range(nb)]
+    check(all(torch.equal(bidx[i], singles[i]) for i in range(nb)), "seeding.batched", restarts=nb, **info)
 
 
 def case_one_thread_mode(rs):
@@ -408,7 +438,8 @@ def case_dropins(rs):
 
 
 CASES = [case_assign, case_sums, case_lloyd, case_best_of_k, case_decode, case_nms, case_relocation, case_seeding,
-         case_one_thread_mode, case_targets, case_fit, case_scene, case_reranked, case_fit_default, case_dropins]
+         case_one_thread_mode, case_targets, case_fit, case_scene, case_reranked, case_fit_default, case_dropins,
+         case_batched_relocation]
 RARE = [case_large, case_seeding_big_k]  # every tenth round
 
 
