@@ -4,7 +4,12 @@
 and ragged row splits (ranks without rows anywhere), unreachable centres (relocation through the all-gathers),
 random check_every, against the one-GPU mtp_lloyd_f32 run of the same case.  Development aid, run on the MI355X box:
 
-    python tests/fuzz_gpu_stub.py [seconds] [seed]
+    python tests/fuzz_gpu_stub.py [seconds] [seed] [loop|fit]
+
+`fit` sweeps the whole row-sharded KMeans(n_clusters, n_init).fit instead (pccs_accel.dist.kmeans_fit_sharded over
+gloo: column statistics handed from rank to rank, k-means++ in lock step with double or reference-order float32
+potentials, every restart's Lloyd run, sklearn's keep-the-best rule) against the one-GPU clustering.kmeans_fit with
+the same random_state.
 
 Not collected by pytest.  Bars: labels and n_iter identical; centres identical on every rank and equal to the
 one-GPU ones to 1e-6 (double sums added in another order); inertia to 1e-9."""
@@ -81,7 +86,81 @@ def worker(rank, world, rdv, seeds, out_dir):
     faulthandler.cancel_dump_traceback_later()
 
 
+def make_fit_case(seed):
+    sys.path[:0] = [os.path.join(ROOT, "tests", "golden")]
+    import datagen
+    rs = np.random.RandomState(seed)
+    order = str(rs.choice(["f64", "openblas"]))
+    n = int(rs.randint(3 * 4096 + 1, 40000)) if order == "openblas" else int(rs.randint(300, 20000))
+    d, k = int(rs.choice([64, 96, 128])), int(rs.randint(2, 60))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    return np.ascontiguousarray(X), k, int(rs.choice([1, 2, 5, 20])), int(rs.randint(1 << 30)), order
+
+
+def fit_worker(rank, world, rdv, seeds, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(170, exit=True)
+    sys.path[:0] = [PKG_DIR]
+    torch.cuda.set_device(0)
+    devc = torch.device("cuda:0")
+    dist.init_process_group("gloo", init_method=f"file://{rdv}", rank=rank, world_size=world)
+    from pccs_accel import dist as pdist
+    from pccs_accel import seeding
+    for seed in seeds:
+        X, k, n_init, state, order = make_fit_case(seed)
+        n = X.shape[0]
+        lo, hi = pdist.shard_bounds(n, rank, world, align=seeding.POT_ALIGN if order == "openblas" else 1)
+        fit = pdist.kmeans_fit_sharded(torch.from_numpy(X[lo:hi].copy()).to(devc), n, row_offset=lo, n_clusters=k,
+                                       n_init=n_init, random_state=state, force_collectives=True, pot_order=order)
+        np.savez(os.path.join(out_dir, f"c{seed}_r{rank}.npz"), labels=fit["labels"].cpu().numpy(),
+                 centers=fit["centers"].cpu().numpy(), inertia=fit["inertia"], n_iter=fit["n_iter"])
+    dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+
+
+def main_fit(budget, seed):
+    sys.path[:0] = [PKG_DIR]
+    from pccs_accel import clustering
+    rs = np.random.RandomState(seed)
+    devc = torch.device("cuda:0")
+    t0 = time.time()
+    n_cases = n_checks = 0
+    fails = []
+    while time.time() - t0 < budget:
+        world = int(rs.choice([2, 3, 4]))  # 4 x 4096-row blocks fit every openblas-order case (n > 3 * 4096)
+        seeds = [int(s) for s in rs.randint(1 << 30, size=4)]
+        fd, rdv = tempfile.mkstemp(prefix="mtp_rdv_")
+        os.close(fd)
+        with tempfile.TemporaryDirectory() as out_dir:
+            mp.spawn(fit_worker, args=(world, rdv, seeds, out_dir), nprocs=world, join=True)
+            for s in seeds:
+                X, k, n_init, state, order = make_fit_case(s)
+                single = clustering.kmeans_fit(torch.from_numpy(X).to(devc), k, n_init=n_init, random_state=state, pot_order=order)
+                parts = [np.load(os.path.join(out_dir, f"c{s}_r{r}.npz")) for r in range(world)]
+                info = dict(seed=s, world=world, n=X.shape[0], d=X.shape[1], k=k, n_init=n_init, order=order)
+                checks = {
+                    "fit.n_iter": all(int(p["n_iter"]) == single["n_iter"] for p in parts),
+                    "fit.replicated": all(np.array_equal(p["centers"], parts[0]["centers"]) for p in parts),
+                    "fit.labels": np.array_equal(np.concatenate([p["labels"] for p in parts]), single["labels"].cpu().numpy()),
+                    "fit.centers": np.allclose(parts[0]["centers"], single["centers"].cpu().numpy(), rtol=1e-6, atol=1e-7),
+                    "fit.inertia": bool(np.isclose(float(parts[0]["inertia"]), single["inertia"], rtol=1e-9)),
+                }
+                for name, ok in checks.items():
+                    n_checks += 1
+                    if not ok:
+                        fails.append((name, info))
+                        print("FAIL", name, info, flush=True)
+                n_cases += 1
+        if os.path.exists(rdv):
+            os.unlink(rdv)
+        print(f"... {n_cases} fits, {n_checks} checks, {len(fails)} failures ({time.time() - t0:.0f} s)", flush=True)
+    print(f"sharded fit sweep: seed {seed}, {n_cases} fits, {n_checks} checks, {len(fails)} failures")
+    sys.exit(1 if fails else 0)
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "fit":
+        main_fit(float(sys.argv[1]), int(sys.argv[2]))
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     sys.path[:0] = [PKG_DIR]
