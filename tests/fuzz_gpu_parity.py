@@ -47,9 +47,18 @@ def pick_d(rs):
     return int(rs.choice([64, 96, 128, 64, 96, 128, int(rs.randint(1, 41)), 4 * int(rs.randint(1, 60))]))
 
 
+def enc(rs, n, d, k_true, spread, noise):
+    """datagen's mixture (integers / 4096), or -- every other time -- the same scaled and jittered into floats
+    with full mantissas, so that no product or sum is exact by construction."""
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, k_true, spread, noise)
+    if rs.rand() < 0.5:
+        X = X * np.float32(rs.uniform(0.3, 3.0)) + (rs.standard_normal(X.shape) * 1e-3).astype(np.float32)
+    return np.ascontiguousarray(X.astype(np.float32))
+
+
 def case_assign(rs):
     n, d, k = int(rs.randint(1, 6000)), pick_d(rs), int(rs.randint(1, 320))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    X = enc(rs, n, d, max(1, k // 2), 1500, 700)
     C = X[rs.randint(0, n, size=k)].copy()
     if rs.rand() < 0.3:  # exact duplicates among the centres: the lowest index must win
         C[rs.randint(0, k)] = C[rs.randint(0, k)]
@@ -64,7 +73,7 @@ def case_assign(rs):
 
 def case_sums(rs):
     n, d, k = int(rs.randint(1, 8000)), pick_d(rs), int(rs.randint(1, 1500))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, 5, 1500, 700)
+    X = enc(rs, n, d, 5, 1500, 700)
     labels = rs.randint(0, k, size=n).astype(np.int32)
     if rs.rand() < 0.3:
         labels[:] = labels[0]  # everything in one cluster
@@ -77,7 +86,7 @@ def case_sums(rs):
 def case_lloyd(rs):
     n, d, k = int(rs.randint(40, 2500)), int(rs.choice([64, 96, 128, 12, 20])), int(rs.randint(1, 40))
     k = min(k, n)
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k), 1500, 700)
+    X = enc(rs, n, d, max(1, k), 1500, 700)
     X = X - X.mean(0)
     C0 = X[rs.choice(n, size=k, replace=False)].copy()
     tol = float(O.tolerance(X)) if rs.rand() < 0.7 else 0.0
@@ -165,7 +174,7 @@ def case_nms(rs):
 def case_relocation(rs):
     """Centres far outside the data start empty: sklearn's relocation (far points in descending distance here)."""
     n, d, k = int(rs.randint(60, 2500)), int(rs.choice([64, 96, 128, 12])), int(rs.randint(3, 40))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    X = enc(rs, n, d, max(1, k // 2), 1500, 700)
     X = X - X.mean(0)
     C0 = X[rs.choice(n, size=k, replace=False)].copy()
     n_far = int(rs.randint(1, k))
@@ -185,7 +194,7 @@ def case_batched_relocation(rs):
     """Restarts of one batch that pause for a relocation at different iterations, beside restarts that never do."""
     n, d, k = int(rs.randint(200, 4000)), int(rs.choice([64, 96, 128])), int(rs.randint(3, 60))
     b = int(rs.choice([2, 4, 7, 12]))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    X = enc(rs, n, d, max(1, k // 2), 1500, 700)
     X = X - X.mean(0)
     tol = float(O.tolerance(X))
     C0s = np.stack([X[rs.choice(n, size=k, replace=False)] for _ in range(b)])
@@ -212,7 +221,7 @@ def case_batched_relocation(rs):
 def case_seeding(rs):
     n, d = int(rs.randint(50, 9000)), int(rs.choice([64, 96, 128, 12, 20, 32]))
     k = int(rs.randint(1, min(n, 48) + 1))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(2, k), 1500, 700)
+    X = enc(rs, n, d, max(2, k), 1500, 700)
     X = X - X.mean(0)
     seed = int(rs.randint(1 << 30))
     _, idx = seeding.kmeans_plusplus(dev(X), k, np.random.RandomState(seed))
@@ -232,7 +241,7 @@ def case_seeding(rs):
 def case_one_thread_mode(rs):
     """sums="sklearn_1t": float32 row-order chains, float32 shift sum and inertia chain -- sklearn on one thread."""
     n, d, k = int(rs.randint(40, 2000)), int(rs.choice([64, 96, 128, 20, 200])), int(rs.randint(1, 30))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k), 1500, 700)
+    X = enc(rs, n, d, max(1, k), 1500, 700)
     X = X - X.mean(0)
     C0 = X[rs.choice(n, size=k, replace=False)].copy()
     if k >= 3 and rs.rand() < 0.4:
@@ -261,7 +270,7 @@ def case_large(rs):
     sums, and a 20-restart batched fit through the restart-grouped E-step (every restart against the oracle)."""
     d = int(rs.choice([64, 96, 128]))
     n, k = int(rs.randint(100_000, 400_000)), int(rs.randint(100, 1100))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, 64, 1500, 700)
+    X = enc(rs, n, d, 64, 1500, 700)
     C = X[rs.randint(0, n, size=k)].copy()
     got = K.assign(dev(X), dev(C)).cpu().numpy()
     want = O.assign(X, C, backend="chain")
@@ -271,7 +280,7 @@ def case_large(rs):
     check(np.array_equal(counts.cpu().numpy(), wc) and np.allclose(sums.cpu().numpy(), ws, rtol=1e-12, atol=1e-12),
           "large.sums", n=n, d=d, k=k)
     nb, kb, b = int(rs.randint(5_000, 30_000)), int(rs.randint(20, 230)), int(rs.choice([5, 12, 20]))
-    Xb = datagen.make_encodings(int(rs.randint(1 << 30)), nb, d, kb, 1500, 700)
+    Xb = enc(rs, nb, d, kb, 1500, 700)
     Xb = Xb - Xb.mean(0)
     tol = float(O.tolerance(Xb))
     C0s = np.stack([Xb[rs.choice(nb, size=kb, replace=False)] for _ in range(b)])
@@ -294,7 +303,7 @@ def case_fit(rs):
     n, d = int(rs.randint(60, 3000)), int(rs.choice([64, 96, 128, 20]))
     k = int(rs.randint(1, min(n, 24) + 1))
     n_init = int(rs.randint(1, 5))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k), 1500, 700)
+    X = enc(rs, n, d, max(1, k), 1500, 700)
     seed = int(rs.randint(1 << 30))
     import warnings
     with warnings.catch_warnings():
@@ -356,7 +365,7 @@ def case_seeding_big_k(rs):
     """More local trials (L = 2 + ln k: 8 from k = 404, 9 from k = 1097: beyond the 8-row candidate tile)."""
     k = int(rs.choice([410, 700, 1100, 1250]))
     n, d = int(rs.randint(k + 10, 4000)), int(rs.choice([64, 96, 128, 20]))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, 40, 1500, 700)
+    X = enc(rs, n, d, 40, 1500, 700)
     X = X - X.mean(0)
     seed = int(rs.randint(1 << 30))
     _, idx = seeding.kmeans_plusplus(dev(X), k, np.random.RandomState(seed))
@@ -371,7 +380,7 @@ def case_fit_default(rs):
     n, d = int(rs.randint(60, 2500)), int(rs.choice([64, 96, 128, 20]))
     k = int(rs.randint(1, min(n, 24) + 1))
     n_init = int(rs.randint(1, 4))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k), 1500, 700)
+    X = enc(rs, n, d, max(1, k), 1500, 700)
     seed = int(rs.randint(1 << 30))
     import warnings
     restarts = []
@@ -403,7 +412,7 @@ def case_dropins(rs):
     check(np.allclose(ade, O.displacement_error(pred[0], gt), rtol=1e-6, atol=0), "dropin.displacement_error", b=b, t=t)
     check(np.allclose(fde, O.final_displacement_error(pred[0][:, -1], gt[:, -1]), rtol=1e-6, atol=0), "dropin.final_displacement_error", b=b, t=t)
     n, d, k = int(rs.randint(30, 400)), int(rs.choice([96, 64, 20])), int(rs.randint(1, 7))
-    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k), 1500, 700)
+    X = enc(rs, n, d, max(1, k), 1500, 700)
     labels = rs.randint(0, k, size=n).astype(np.int32)
     labels[:k] = np.arange(k)                                         # no empty cluster (KeyError otherwise, tested elsewhere)
     mod = get_modality(torch.from_numpy(X), labels, k).numpy()
@@ -437,9 +446,74 @@ def case_dropins(rs):
         check(got[0].dtype == np.int32 and got[1].dtype == np.int64 and int(got[1].sum()) == n, "dropin.cluster_data.dtypes", n=n, k=k)
 
 
+def case_primitives(rs):
+    """The small entry points of the fit's pre- and post-processing, each against NumPy / the oracle."""
+    n, d = int(rs.randint(1, 5000)), pick_d(rs)
+    X = enc(rs, n, d, 5, 1500, 700)
+    info = dict(n=n, d=d)
+    check(np.array_equal(K.row_sqnorm(dev(X)).cpu().numpy(), np.einsum("ij,ij->i", X, X)), "prim.row_sqnorm_bits", **info)
+    X64 = X.astype(np.float64)
+    cs = K.col_sums(dev(X))
+    check(np.allclose(cs.cpu().numpy(), X64.sum(axis=0), rtol=1e-12, atol=1e-12), "prim.col_sums", **info)
+    mean64 = X64.mean(axis=0)
+    sq = K.col_sqdev(dev(X), dev(mean64))
+    check(np.allclose(sq.cpu().numpy(), ((X64 - mean64) ** 2).sum(axis=0), rtol=1e-11, atol=1e-12), "prim.col_sqdev", **info)
+    vec = mean64.astype(np.float32)
+    check(np.array_equal(K.sub_rowvec_(dev(X), dev(vec)).cpu().numpy(), X - vec), "prim.sub_rowvec_bits", **info)
+    k = int(rs.randint(1, 300))
+    labels = rs.randint(0, k, size=n).astype(np.int32)
+    sums, counts = K.centroid_sums(dev(X), dev(labels), k)
+    means, n_empty = K.cluster_means(sums, counts)
+    hs, hc = sums.cpu().numpy(), counts.cpu().numpy()
+    full = hc > 0
+    check(int(n_empty.item()) == int((~full).sum()), "prim.cluster_means.n_empty", k=k, **info)
+    check(np.array_equal(means.cpu().numpy()[full], (hs[full] / hc[full, None]).astype(np.float32)), "prim.cluster_means_bits", k=k, **info)
+    # is_same_clustering: a relabelling, and the same with one point moved
+    perm = rs.permutation(k).astype(np.int32)
+    l2 = perm[labels]
+    check(clustering.is_same_clustering(dev(labels), dev(l2), k) is True, "prim.same_clustering", k=k, **info)
+    if n >= 2 and k >= 2:
+        l3 = l2.copy()
+        j = int(rs.randint(n))
+        l3[j] = (l3[j] + 1 + rs.randint(k - 1)) % k
+        want = O.is_same_clustering(labels, l3, k)
+        check(clustering.is_same_clustering(dev(labels), dev(l3), k) == want, "prim.same_clustering.moved", k=k, want=want, **info)
+    # per-candidate ADE / FDE
+    na, ka, t = int(rs.randint(1, 800)), int(rs.randint(1, 40)), int(rs.choice([12, 8, 1, 20]))
+    pred, gt = datagen.make_trajectories(int(rs.randint(1 << 30)), na, ka, t, dtype=np.float32)
+    div = float(rs.choice([1.0, float(t)]))
+    best_of = None if rs.rand() < 0.5 else int(rs.randint(1, ka + 1))
+    ga, gf = K.ade_fde(dev(pred), dev(gt), ade_div=div, best_of=best_of)
+    oa, of = O.ade_fde(pred, gt, ade_div=div, best_of=best_of)
+    check(np.allclose(ga.cpu().numpy(), oa, rtol=1e-5, atol=0), "prim.ade", n=na, k=ka, t=t, best_of=best_of)
+    check(np.allclose(gf.cpu().numpy(), of, rtol=1e-5, atol=0), "prim.fde", n=na, k=ka, t=t, best_of=best_of)
+
+
+def case_noalloc(rs):
+    """mtp_assign_noalloc_f32 against mtp_assign_f32, two calls in a row on the shared built-in buffer."""
+    from pccs_accel._lib import lib, ptr, stream_ptr
+    for _ in range(2):
+        d = pick_d(rs)
+        k = int(rs.randint(1, 1500))
+        while int(lib().mtp_assign_workspace_bytes(k, d)) > (1 << 20):
+            k = max(1, k // 2)
+        n = int(rs.randint(1, 6000))
+        X = enc(rs, n, d, max(1, k // 2), 1500, 700)
+        C = X[rs.randint(0, n, size=k)].copy()
+        prev = rs.randint(0, k, size=n).astype(np.int32)
+        Xd, Cd = dev(X), dev(C)
+        want, got = dev(prev), dev(prev)
+        wch = torch.zeros(1, dtype=torch.float64, device=DEV)
+        gch = torch.zeros(1, dtype=torch.float64, device=DEV)
+        K.assign(Xd, Cd, labels=want, n_changed=wch)
+        rc = lib().mtp_assign_noalloc_f32(ptr(Xd), n, d, ptr(Cd), k, ptr(got), ptr(gch), stream_ptr())
+        torch.cuda.synchronize()
+        check(rc == 0 and torch.equal(got, want) and float(gch.item()) == float(wch.item()), "noalloc.assign", n=n, d=d, k=k, rc=rc)
+
+
 CASES = [case_assign, case_sums, case_lloyd, case_best_of_k, case_decode, case_nms, case_relocation, case_seeding,
          case_one_thread_mode, case_targets, case_fit, case_scene, case_reranked, case_fit_default, case_dropins,
-         case_batched_relocation]
+         case_batched_relocation, case_primitives, case_noalloc]
 RARE = [case_large, case_seeding_big_k]  # every tenth round
 
 
