@@ -170,8 +170,8 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
         group = int(max(1, min(n_init, 16e9 // (2.0 * l * n * 4))))  # closest-distance rows: 2 * L * N floats each
         for s0 in range(0, n_init, group):
             c0s, idx = seeding.kmeans_plusplus_batched(Xc, n_clusters, draws[s0:s0 + group], pot_order=pot_order)
-            for b in range(c0s.shape[0]):
-                consider(*K.lloyd(Xc, c0s[b].contiguous(), max_iter=max_iter, tol_abs=tol_abs, check_every=check_every,
+            for b in range(c0s.shape[0]):  # a copy: row b of the batch starts 16-byte aligned only when 4 | K * D
+                consider(*K.lloyd(Xc, c0s[b].clone(), max_iter=max_iter, tol_abs=tol_abs, check_every=check_every,
                                   sums=sums), indices=idx[b])
             del c0s
     else:

@@ -535,7 +535,7 @@ def kmeans_fit_sharded(X_local, n_total, C0=None, row_offset=0, tol=1e-4, max_it
                                              force_collectives=force_collectives, pot_order=pot_order)
     best = None
     for r in range(n_init):
-        labels, inertia, centers, n_iter = lloyd(c0s[r].contiguous())
+        labels, inertia, centers, n_iter = lloyd(c0s[r].clone())  # a copy: row r starts 16-byte aligned only when 4 | K * D
         if best is None or (inertia < best["inertia"] and not is_same_clustering_sharded(
                 labels, best["labels"], n_clusters, collective, group)):
             best = dict(labels=labels.clone(), centers=centers.clone(), inertia=inertia, n_iter=n_iter)

@@ -300,7 +300,7 @@ def case_large(rs):
 
 def case_fit(rs):
     """Whole seeded fits: column statistics in NumPy's order, k-means++ x n_init, Lloyd, sklearn's restart rule."""
-    n, d = int(rs.randint(60, 3000)), int(rs.choice([64, 96, 128, 20]))
+    n, d = int(rs.randint(60, 3000)), int(rs.choice([64, 96, 128, 20, 23, 7]))
     k = int(rs.randint(1, min(n, 24) + 1))
     n_init = int(rs.randint(1, 5))
     X = enc(rs, n, d, max(1, k), 1500, 700)
@@ -377,7 +377,7 @@ def case_seeding_big_k(rs):
 
 def case_fit_default(rs):
     """The default mode (double sums) restart by restart against the oracle's same variant: seeds, n_iter, labels."""
-    n, d = int(rs.randint(60, 2500)), int(rs.choice([64, 96, 128, 20]))
+    n, d = int(rs.randint(60, 2500)), int(rs.choice([64, 96, 128, 20, 23, 7]))
     k = int(rs.randint(1, min(n, 24) + 1))
     n_init = int(rs.randint(1, 4))
     X = enc(rs, n, d, max(1, k), 1500, 700)

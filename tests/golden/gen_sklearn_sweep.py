@@ -1,0 +1,74 @@
+"""Generate tests/golden/g30_sklearn_sweep.npz: scikit-learn's own KMeans on ONE thread over seeded random shapes.
+
+Run ONLY in the build container (needs scikit-learn 1.7.2, the third-party package that holds the reference's
+k-means arithmetic, PCCSNet/utils/utility.py:121):
+
+    python tests/golden/gen_sklearn_sweep.py [count] [seed]
+
+For every case it draws (n, d, K, n_init, random_state) and the points (datagen's integer mixture, every other time
+scaled and jittered into floats with full mantissas), runs ``KMeans(K, n_init=n_init, random_state=s).fit(X)`` under
+``threadpool_limits(1)`` -- the deterministic run that the product's ``sums="sklearn_1t"`` mode reproduces bit for bit
+(fixture G15 holds six reference-sized ones) -- and stores the parameters, a digest of the points, and of the result:
+n_iter, the inertia's bits, digests of the labels and of the centres, the cluster sizes' digest.  Data only.
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import datagen  # noqa: E402
+
+
+def crc(a, dtype):
+    return zlib.crc32(np.ascontiguousarray(a, dtype=dtype).tobytes())
+
+
+def draw_case(seed):
+    """The parameters and points of case ``seed``; the same in the generator and in the test."""
+    rs = np.random.RandomState(seed)
+    n = int(rs.randint(60, 9000))
+    d = int(rs.choice([64, 96, 128, 96, int(rs.randint(2, 41)), 4 * int(rs.randint(1, 60))]))
+    k = int(min(rs.randint(2, 120), n // 3))
+    n_init = int(rs.choice([1, 2, 3, 5]))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    if rs.rand() < 0.5:
+        X = X * np.float32(rs.uniform(0.3, 3.0)) + (rs.standard_normal(X.shape) * 1e-3).astype(np.float32)
+    X = np.ascontiguousarray(X.astype(np.float32))
+    return X, k, n_init, int(rs.randint(1 << 30))
+
+
+def main():
+    import sklearn
+    from sklearn.cluster import KMeans
+    from threadpoolctl import threadpool_info, threadpool_limits
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    seeds = [int(s) for s in np.random.RandomState(seed0).randint(1 << 30, size=count)]
+    blas = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+    stack = "numpy %s; scikit-learn %s; %s" % (np.__version__, sklearn.__version__, "; ".join(
+        "%s %s core=%s" % (i.get("internal_api"), i.get("version"), i.get("architecture")) for i in blas))
+    rec = {key: [] for key in ("n", "d", "k", "n_init", "x_crc", "n_iter", "inertia", "labels_crc", "centers_crc", "sizes_crc")}
+    with threadpool_limits(limits=1):
+        for i, s in enumerate(seeds):
+            X, k, n_init, state = draw_case(s)
+            km = KMeans(n_clusters=k, n_init=n_init, random_state=state).fit(X)
+            again = KMeans(n_clusters=k, n_init=n_init, random_state=state).fit(X)   # deterministic on one thread?
+            assert np.array_equal(km.labels_, again.labels_) and km.inertia_ == again.inertia_
+            for key, v in (("n", X.shape[0]), ("d", X.shape[1]), ("k", k), ("n_init", n_init), ("x_crc", crc(X, np.float32)),
+                           ("n_iter", km.n_iter_), ("inertia", np.float64(km.inertia_)), ("labels_crc", crc(km.labels_, np.int32)),
+                           ("centers_crc", crc(km.cluster_centers_, np.float32)),
+                           ("sizes_crc", crc(np.bincount(km.labels_, minlength=k), np.int64))):
+                rec[key].append(v)
+            if i % 20 == 0:
+                print(i, X.shape, k, n_init, km.n_iter_, flush=True)
+    p = os.path.join(HERE, "g30_sklearn_sweep.npz")
+    np.savez_compressed(p, seeds=np.asarray(seeds, dtype=np.int64), stack=np.asarray(stack),
+                        **{key: np.asarray(v, dtype=np.float64 if key == "inertia" else np.int64) for key, v in rec.items()})
+    print("wrote", p, os.path.getsize(p), "bytes;", stack)
+
+
+if __name__ == "__main__":
+    main()

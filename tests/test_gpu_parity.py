@@ -547,6 +547,26 @@ def test_kmeans_fit_rejects_non_finite_input_like_sklearn(gpu_device):
         kmeans_fit(X[:3].contiguous(), 4, n_init=1)
 
 
+@pytest.mark.parametrize("d,k", [(23, 5), (7, 3), (10, 3)])
+def test_kmeans_fit_with_restarts_whose_seed_rows_start_unaligned(d, k, gpu_device):
+    """K * D not a multiple of 4: restart r's seeds start r * K * D floats into the batch the seeding returns, off the
+    16-byte grid the Lloyd entry asks for (the fit hands it a copy; it used to hand it the view and be refused --
+    found by the sweep against sklearn, fixture G30).  Every restart against the oracle's: seeds, n_iter, labels."""
+    from pccs_accel.clustering import kmeans_fit
+    X = datagen.make_encodings(77, 1500, d, 4, 1500, 700)
+    restarts = []
+    kmeans_fit(dev(X, gpu_device), k, n_init=4, random_state=9, restarts_out=restarts)
+    Xc = X - X.mean(axis=0)
+    tol = float(O.tolerance(X))
+    rs = np.random.RandomState(9)
+    assert len(restarts) == 4
+    for r in restarts:
+        c0, idx = O.kmeans_plusplus(Xc, k, rs)
+        ol, _, _, on = O.kmeans_single_lloyd(Xc, c0, 300, tol, sums="f64", far_order="descending")
+        assert np.array_equal(r["indices"].cpu().numpy(), idx)
+        assert r["n_iter"] == on and np.array_equal(r["labels"].cpu().numpy(), ol)
+
+
 @pytest.mark.parametrize("n,k", [(53, 12), (1, 1), (4097, 200), (1000, 7), (0, 5)])
 def test_classifier_targets_match_reference_expression(n, k, gpu_device):
     """mtp_label_targets_f32 behind classifier_targets: int64 labels and the one-hot [N, K] targets of

@@ -1,0 +1,39 @@
+"""240 seeded random fits against scikit-learn itself (fixture G30, tests/golden/gen_sklearn_sweep.py: sklearn 1.7.2's
+``KMeans(K, n_init, random_state).fit`` held to one thread, where it is deterministic).  The fixture stores digests
+only; the points are rebuilt from the case seed (their digest is asserted first).  The product's
+``sums="sklearn_1t"`` mode must give sklearn's result bit for bit: iteration count, inertia, labels, cluster sizes and
+the centres ``cluster_centers_`` -- for feature sizes on and off the MFMA path, integer-built and full-mantissa points,
+1-5 restarts.  G15 does the same at the reference's six sizes."""
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+sys.path.insert(0, GOLDEN)
+from gen_sklearn_sweep import crc, draw_case  # noqa: E402  (the case generator only; sklearn is not imported)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_fits_bit_equal_to_sklearn_on_one_thread(gpu_device):
+    from pccs_accel import clustering
+    g = load_golden("g30_sklearn_sweep")
+    bad = []
+    for i, s in enumerate(g["seeds"]):
+        X, k, n_init, state = draw_case(int(s))
+        assert (X.shape[0], X.shape[1], k, n_init) == (int(g["n"][i]), int(g["d"][i]), int(g["k"][i]), int(g["n_init"][i]))
+        assert crc(X, np.float32) == int(g["x_crc"][i]), f"case {i}: the points are not the generator's"
+        fit = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), k, n_init=n_init, random_state=state, sums="sklearn_1t")
+        labels = fit["labels"].cpu().numpy()
+        got = dict(n_iter=fit["n_iter"] == int(g["n_iter"][i]), inertia=fit["inertia"] == float(g["inertia"][i]),
+                   labels=crc(labels, np.int32) == int(g["labels_crc"][i]),
+                   sizes=crc(np.bincount(labels, minlength=k), np.int64) == int(g["sizes_crc"][i]),
+                   centers=crc(fit["centers"].cpu().numpy(), np.float32) == int(g["centers_crc"][i]))
+        if not all(got.values()):
+            bad.append((i, int(s), X.shape, k, n_init, [name for name, ok in got.items() if not ok]))
+    assert not bad, f"{len(bad)} of {len(g['seeds'])} fits differ from sklearn's: {bad[:10]}"
