@@ -3,13 +3,20 @@
 Run ONLY in the build container (needs scikit-learn 1.7.2, the third-party package that holds the reference's
 k-means arithmetic, PCCSNet/utils/utility.py:121):
 
-    python tests/golden/gen_sklearn_sweep.py [count] [seed]
+    python tests/golden/gen_sklearn_sweep.py [count] [seed]            # G30, 240 cases from seed 30
+    python tests/golden/gen_sklearn_sweep.py [count] [seed] init       # G31, 160 cases from seed 31
 
 For every case it draws (n, d, K, n_init, random_state) and the points (datagen's integer mixture, every other time
 scaled and jittered into floats with full mantissas), runs ``KMeans(K, n_init=n_init, random_state=s).fit(X)`` under
 ``threadpool_limits(1)`` -- the deterministic run that the product's ``sums="sklearn_1t"`` mode reproduces bit for bit
 (fixture G15 holds six reference-sized ones) -- and stores the parameters, a digest of the points, and of the result:
 n_iter, the inertia's bits, digests of the labels and of the centres, the cluster sizes' digest.  Data only.
+
+``init`` (fixture G31): ``KMeans(K, init=C0, n_init=1).fit(X)`` from given centres instead -- rows of X, one of them
+moved out of reach, so that its cluster starts empty and sklearn relocates it to the point farthest from its centre
+(_k_means_common.pyx:165-200; ONE empty cluster at a time: with more, np.argpartition leaves their order to the
+CPU's SIMD selection kernel) -- over points a third of which may be exact duplicates of other rows (equal distances
+in the E-step: the lowest label wins, _k_means_lloyd.pyx:197-199).
 """
 import os
 import sys
@@ -40,7 +47,54 @@ def draw_case(seed):
     return X, k, n_init, int(rs.randint(1 << 30))
 
 
+def draw_init_case(seed):
+    """(X, C0): the points and initial centres of G31's case ``seed``."""
+    rs = np.random.RandomState(seed)
+    n = int(rs.randint(60, 7000))
+    d = int(rs.choice([64, 96, 128, 96, int(rs.randint(2, 41)), 4 * int(rs.randint(1, 60))]))
+    k = int(min(rs.randint(3, 100), n // 3))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    if rs.rand() < 0.5:
+        X = X * np.float32(rs.uniform(0.3, 3.0)) + (rs.standard_normal(X.shape) * 1e-3).astype(np.float32)
+    X = np.ascontiguousarray(X.astype(np.float32))
+    if rs.rand() < 0.4:  # exact duplicates of other rows
+        m = n // 3
+        X[rs.randint(0, n, size=m)] = X[rs.randint(0, n, size=m)]
+    C0 = X[rs.choice(n, size=k, replace=False)].copy()
+    if rs.rand() < 0.7:
+        C0[int(rs.randint(k))] += np.float32(50.0)
+    return X, C0
+
+
+def main_init(count, seed0):
+    import sklearn
+    from sklearn.cluster import KMeans
+    from threadpoolctl import threadpool_limits
+    seeds = [int(s) for s in np.random.RandomState(seed0).randint(1 << 30, size=count)]
+    rec = {key: [] for key in ("n", "d", "k", "x_crc", "n_iter", "inertia", "labels_crc", "centers_crc", "sizes_crc")}
+    with threadpool_limits(limits=1):
+        for i, s in enumerate(seeds):
+            X, C0 = draw_init_case(s)
+            k = C0.shape[0]
+            km = KMeans(n_clusters=k, init=C0.copy(), n_init=1).fit(X)
+            again = KMeans(n_clusters=k, init=C0.copy(), n_init=1).fit(X)
+            assert np.array_equal(km.labels_, again.labels_) and km.inertia_ == again.inertia_
+            for key, v in (("n", X.shape[0]), ("d", X.shape[1]), ("k", k), ("x_crc", crc(X, np.float32)),
+                           ("n_iter", km.n_iter_), ("inertia", np.float64(km.inertia_)), ("labels_crc", crc(km.labels_, np.int32)),
+                           ("centers_crc", crc(km.cluster_centers_, np.float32)),
+                           ("sizes_crc", crc(np.bincount(km.labels_, minlength=k), np.int64))):
+                rec[key].append(v)
+            if i % 20 == 0:
+                print(i, X.shape, k, km.n_iter_, flush=True)
+    p = os.path.join(HERE, "g31_sklearn_init_sweep.npz")
+    np.savez_compressed(p, seeds=np.asarray(seeds, dtype=np.int64), stack=np.asarray("scikit-learn " + sklearn.__version__),
+                        **{key: np.asarray(v, dtype=np.float64 if key == "inertia" else np.int64) for key, v in rec.items()})
+    print("wrote", p, os.path.getsize(p), "bytes")
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "init":
+        return main_init(int(sys.argv[1]), int(sys.argv[2]))
     import sklearn
     from sklearn.cluster import KMeans
     from threadpoolctl import threadpool_info, threadpool_limits
