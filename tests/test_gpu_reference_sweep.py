@@ -1,0 +1,48 @@
+"""200 seeded random scene sets against the reference's own ``process_scene`` / ``gen_prob`` (fixture G32,
+tests/golden/gen_reference_sweep.py imports them from the reference; the fixture holds digests).  The drop-ins named
+like the reference's functions (pccs_accel.scene.process_scene / gen_prob, on top of mtp_scene_neighbors_f32 and
+mtp_scene_soft_labels) must return the reference's neighbour dict, per-sample classes in first-seen order, their
+probabilities and the dense soft labels bit for bit -- 103 111 neighbour entries over 1-4 scenes of 1-120 pedestrians,
+three observation lengths, four radii, integer-built and full-mantissa positions.  G12 is the one fixed case."""
+import argparse
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+sys.path.insert(0, GOLDEN)
+from gen_reference_sweep import crc, digests, draw_scene_case  # noqa: E402  (case generator and digests only)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_scenes_bit_equal_to_the_reference(gpu_device, tmp_path):
+    from pccs_accel import scene
+    g = load_golden("g32_scene_sweep")
+    os.makedirs(tmp_path / "ethucy" / "toy")
+    bad = []
+    for i, s in enumerate(g["seeds"]):
+        trj, marks, obs_len, rad, k, labels = draw_scene_case(int(s))
+        n = len(trj)
+        assert (n, obs_len, rad, k) == (int(g["n"][i]), int(g["obs_len"][i]), float(g["rad"][i]), int(g["k"][i]))
+        assert crc(trj, np.float32) == int(g["x_crc"][i]), f"case {i}: the positions are not the generator's"
+        args = argparse.Namespace(obs_len=obs_len, pred_len=20 - obs_len, data_from="ethucy", rad=rad, n_cluster=k)
+        train_set = argparse.Namespace(trj_data=torch.from_numpy(trj).float(), split_marks=marks)
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = scene.process_scene("toy", train_set, args, save_dir=str(tmp_path))
+        res_class, res_prob = scene.gen_prob(res, labels, str(tmp_path))
+        got = digests(n, k, res, res_class, res_prob)
+        diff = [key for key, v in got.items() if v != int(g[key][i])]
+        # the dense labels straight from the kernel as well (get_scene_data's array, data_process.py:212-218)
+        offsets, ids = scene.scene_neighbors(trj, marks, obs_len, rad)
+        if crc(scene.soft_labels(offsets, ids, labels, k).cpu().numpy(), np.float64) != int(g["dense_crc"][i]):
+            diff.append("dense from the kernel")
+        if diff:
+            bad.append((i, int(s), n, obs_len, rad, diff))
+    assert not bad, f"{len(bad)} of {len(g['seeds'])} scene sets differ from the reference's: {bad[:10]}"
