@@ -2,13 +2,19 @@
 
 Run ONLY in the build container (imports PCCSNet/utils/data_process.py from /root/reference, never copies it):
 
-    python tests/golden/gen_reference_sweep.py [count] [seed]
+    python tests/golden/gen_reference_sweep.py [count] [seed]            # G32, 200 cases from seed 32
+    python tests/golden/gen_reference_sweep.py [count] [seed] metrics    # G33, 60 cases from seed 33
 
 Every case draws 1-4 scenes of 1-120 pedestrians (datagen.make_scene_trajectories, every other time jittered into
 positions with full mantissas), an observation length, a radius, a cluster count and random cluster labels, runs the
 reference's ``process_scene`` (:134-169) and ``gen_prob`` (:172-192), builds the dense soft labels the way
 ``get_scene_data`` does (:212-218) and stores the parameters, a digest of the positions and digests of the results:
 neighbour offsets and ids, classes, probabilities, dense labels.  Data only.
+
+``metrics`` (fixture G33): the evaluation loop of PCCSNet/train_steps.py:214-232 with batch size 1 around the
+reference's imported ``displacement_error`` / ``final_displacement_error`` (utils/metrics.py:4-23), in its three
+modes, on seeded random candidate sets with full-mantissa coordinates (1-300 agents, 1-40 candidates, 1-20 steps):
+per agent the chosen candidate and its (ADE, FDE), and the means the loop reports.
 """
 import argparse
 import contextlib
@@ -61,7 +67,72 @@ def digests(n, k, neighbours, res_class, res_prob):
                 dense_crc=crc(dense, np.float64))
 
 
+def draw_metrics_case(seed):
+    """(pred float32 [n, k, t, 2], gt float32 [n, t, 2]) of G33's case ``seed``."""
+    rs = np.random.RandomState(seed)
+    n, k, t = int(rs.randint(1, 301)), int(rs.randint(1, 41)), int(rs.choice([12, 12, 8, 20, 5, 1]))
+    pred, gt = datagen.make_trajectories(int(rs.randint(1 << 30)), n, k, t)
+    scale = np.float32(rs.uniform(0.3, 3.0))
+    pred = pred * scale + (rs.standard_normal(pred.shape) * 1e-2).astype(np.float32)
+    gt = gt * scale + (rs.standard_normal(gt.shape) * 1e-2).astype(np.float32)
+    return np.ascontiguousarray(pred.astype(np.float32)), np.ascontiguousarray(gt.astype(np.float32))
+
+
+def main_metrics(count, seed0):
+    import torch
+    for m in [m for m in sys.modules if m == "utils" or m.startswith("utils.")]:
+        del sys.modules[m]
+    sys.path.insert(0, os.path.join(REF, "PCCSNet"))
+    try:
+        metrics = importlib.import_module("utils.metrics")
+    finally:
+        sys.path.remove(os.path.join(REF, "PCCSNet"))
+    seeds = [int(s) for s in np.random.RandomState(seed0).randint(1 << 30, size=count)]
+    out = dict(seeds=np.asarray(seeds, dtype=np.int64), n=[], k=[], t=[], x_crc=[], off=[0])
+    per_mode = {m: dict(mins=[], idx=[], val=[]) for m in (0, 1, 2)}
+    for s in seeds:
+        pred, gt = draw_metrics_case(s)
+        n, k, t = pred.shape[:3]
+        tp, tg = torch.from_numpy(pred), torch.from_numpy(gt)
+        for mode in (0, 1, 2):
+            val = np.zeros(2).astype(float)
+            mins = np.empty((n, 2), dtype=np.float32)
+            idx = np.empty(n, dtype=np.int64)
+            for i in range(n):  # PCCSNet/train_steps.py:214-232 with batch_size 1
+                o, g = tp[i], tg[i:i + 1]
+                A = metrics.displacement_error(o, g) / t
+                F = metrics.final_displacement_error(o[:, -1], g[:, -1])
+                if mode == 0:
+                    j = torch.argmin(A)
+                    a, f = A[j].item(), F[j].item()
+                elif mode == 1:
+                    j = torch.argmin(F)
+                    a, f = A[j].item(), F[j].item()
+                else:
+                    j = torch.argmin(A)
+                    a, f = torch.min(A).item(), torch.min(F).item()
+                val += [a, f]
+                mins[i] = (a, f)
+                idx[i] = int(j)
+            per_mode[mode]["mins"].append(mins)
+            per_mode[mode]["idx"].append(idx)
+            per_mode[mode]["val"].append(val / n)
+        for key, v in (("n", n), ("k", k), ("t", t), ("x_crc", crc(pred, np.float32) ^ crc(gt, np.float32))):
+            out[key].append(v)
+        out["off"].append(out["off"][-1] + n)
+    arrays = {key: np.asarray(v, dtype=np.int64) for key, v in out.items()}
+    for mode in (0, 1, 2):
+        arrays[f"mode{mode}_mins"] = np.concatenate(per_mode[mode]["mins"])
+        arrays[f"mode{mode}_idx"] = np.concatenate(per_mode[mode]["idx"]).astype(np.int32)
+        arrays[f"mode{mode}_val"] = np.stack(per_mode[mode]["val"])
+    p = os.path.join(HERE, "g33_metrics_sweep.npz")
+    np.savez_compressed(p, **arrays)
+    print("wrote", p, os.path.getsize(p), "bytes;", int(arrays["off"][-1]), "agents")
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "metrics":
+        return main_metrics(int(sys.argv[1]), int(sys.argv[2]))
     import torch
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 32

@@ -17,7 +17,7 @@ import torch
 from conftest import GOLDEN, load_golden
 
 sys.path.insert(0, GOLDEN)
-from gen_reference_sweep import crc, digests, draw_scene_case  # noqa: E402  (case generator and digests only)
+from gen_reference_sweep import crc, digests, draw_metrics_case, draw_scene_case  # noqa: E402  (case generators and digests only)
 
 pytestmark = pytest.mark.gpu
 
@@ -46,3 +46,25 @@ def test_random_scenes_bit_equal_to_the_reference(gpu_device, tmp_path):
         if diff:
             bad.append((i, int(s), n, obs_len, rad, diff))
     assert not bad, f"{len(bad)} of {len(g['seeds'])} scene sets differ from the reference's: {bad[:10]}"
+
+
+def test_random_candidate_sets_against_the_reference_metrics(gpu_device):
+    """Fixture G33: the evaluation loop of PCCSNet/train_steps.py:214-232 around the reference's imported
+    displacement_error / final_displacement_error, three modes, on 60 seeded random candidate sets with full-mantissa
+    coordinates (8 755 agents, 1-40 candidates, 1-20 steps).  mtp_best_of_k_f32 must choose the reference's candidate
+    for every agent in every mode (bit-exact indices) and give its ADE / FDE and the reported means to 1e-5."""
+    from pccs_accel.evaluation import best_of_k
+    g = load_golden("g33_metrics_sweep")
+    for i, s in enumerate(g["seeds"]):
+        pred, gt = draw_metrics_case(int(s))
+        assert pred.shape[:3] == (int(g["n"][i]), int(g["k"][i]), int(g["t"][i]))
+        assert crc(pred, np.float32) ^ crc(gt, np.float32) == int(g["x_crc"][i]), f"case {i}: not the generator's inputs"
+        lo, hi = int(g["off"][i]), int(g["off"][i + 1])
+        tp, tg = torch.from_numpy(pred).to(gpu_device), torch.from_numpy(gt).to(gpu_device)
+        for mode in (0, 1, 2):
+            min_ade, min_fde, idx, mean_ade, mean_fde = best_of_k(tp, tg, mode=mode)
+            info = (i, pred.shape, mode)
+            assert np.array_equal(idx.cpu().numpy(), g[f"mode{mode}_idx"][lo:hi]), info
+            assert np.allclose(min_ade.cpu().numpy(), g[f"mode{mode}_mins"][lo:hi, 0], rtol=1e-5, atol=0), info
+            assert np.allclose(min_fde.cpu().numpy(), g[f"mode{mode}_mins"][lo:hi, 1], rtol=1e-5, atol=0), info
+            assert np.allclose([mean_ade, mean_fde], g[f"mode{mode}_val"][i], rtol=1e-5, atol=0), info
