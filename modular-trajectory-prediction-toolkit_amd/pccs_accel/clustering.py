@@ -200,13 +200,21 @@ def kmeans_fit(X, n_clusters, n_init=20, init="k-means++", random_state=None, ma
 # ------------------------------------------------------------------------------------------
 # The reference's call sites
 # ------------------------------------------------------------------------------------------
+# Summation mode of the reference-named call sites below (their signatures are the reference's and have no room
+# for it): "f64" (``kmeans_fit``'s default) or "sklearn_1t" -- the reference stack on one thread, bit for bit.
+# Set the attribute, or PCCS_ACCEL_SUMS in the environment before the import.
+SUMS = os.environ.get("PCCS_ACCEL_SUMS", "f64")
+
+
 def k_means_cluster(data, n_clusters, init=20):
     """PCCSNet/utils/utility.py:120-133.  ``init`` is sklearn's n_init.
 
     Returns (cluster_result np.int32 [N], size_array np.int64 [K]); raises KeyError(i) when
     cluster i ends up empty, as the reference's ``res[i]`` lookup does."""
+    if SUMS not in ("f64", "sklearn_1t"):
+        raise ValueError(f"pccs_accel.clustering.SUMS must be 'f64' or 'sklearn_1t', got {SUMS!r}")
     X = _as_device_f32(data)
-    fit = kmeans_fit(X, n_clusters, n_init=init)
+    fit = kmeans_fit(X, n_clusters, n_init=init, sums=SUMS)
     labels = fit["labels"]
     sizes = torch.bincount(labels.to(torch.int64), minlength=n_clusters).cpu().numpy().astype(np.int64)
     for i in range(n_clusters):

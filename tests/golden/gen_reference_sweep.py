@@ -4,6 +4,7 @@ Run ONLY in the build container (imports PCCSNet/utils/data_process.py from /roo
 
     python tests/golden/gen_reference_sweep.py [count] [seed]            # G32, 200 cases from seed 32
     python tests/golden/gen_reference_sweep.py [count] [seed] metrics    # G33, 60 cases from seed 33
+    python tests/golden/gen_reference_sweep.py [count] [seed] cluster    # G34, 80 cases from seed 34
 
 Every case draws 1-4 scenes of 1-120 pedestrians (datagen.make_scene_trajectories, every other time jittered into
 positions with full mantissas), an observation length, a radius, a cluster count and random cluster labels, runs the
@@ -15,6 +16,11 @@ neighbour offsets and ids, classes, probabilities, dense labels.  Data only.
 reference's imported ``displacement_error`` / ``final_displacement_error`` (utils/metrics.py:4-23), in its three
 modes, on seeded random candidate sets with full-mantissa coordinates (1-300 agents, 1-40 candidates, 1-20 steps):
 per agent the chosen candidate and its (ADE, FDE), and the means the loop reports.
+
+``cluster`` (fixture G34): ``np.random.seed(s); cluster_data(X, K)`` of PCCSNet/utils/utility.py:108-133 and, every
+other case, the XOE copy with ``args.pm`` / ``args.obs_feat_size`` (MomentaryPrediction/PCCSNet_XOE/utils/utility.py),
+both imported and run under ``threadpool_limits(1)`` (20 restarts, deterministic on one thread) on seeded random
+encodings: digests of the labels and of the size array.
 """
 import argparse
 import contextlib
@@ -130,7 +136,57 @@ def main_metrics(count, seed0):
     print("wrote", p, os.path.getsize(p), "bytes;", int(arrays["off"][-1]), "agents")
 
 
+def draw_cluster_case(seed):
+    """(X float32 [n, d], K, np.random seed, pm or None, obs_feat_size) of G34's case ``seed``."""
+    rs = np.random.RandomState(seed)
+    n, d = int(rs.randint(300, 6000)), int(rs.choice([96, 96, 64, 128, 48, 20]))
+    k = int(rs.randint(2, 41))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2 + int(rs.randint(0, k))), 1500, 700)
+    if rs.rand() < 0.5:
+        X = X * np.float32(rs.uniform(0.3, 3.0)) + (rs.standard_normal(X.shape) * 1e-3).astype(np.float32)
+    X = np.ascontiguousarray(X.astype(np.float32))
+    pm = float(rs.choice([0.02, 0.5, 1.5])) if rs.rand() < 0.5 else None
+    return X, k, int(rs.randint(1 << 30)), pm, d // 2
+
+
+def main_cluster(count, seed0):
+    from threadpoolctl import threadpool_limits
+    mods = {}
+    for name, root, mod in (("pccs", os.path.join(REF, "PCCSNet"), "utils.utility"),
+                            ("xoe", os.path.join(REF, "MomentaryPrediction"), "PCCSNet_XOE.utils.utility")):
+        for m in [m for m in sys.modules if m == "utils" or m.startswith("utils.")]:
+            del sys.modules[m]
+        sys.path.insert(0, root)
+        try:
+            mods[name] = importlib.import_module(mod)
+        finally:
+            sys.path.remove(root)
+    seeds = [int(s) for s in np.random.RandomState(seed0).randint(1 << 30, size=count)]
+    rec = {}
+    with threadpool_limits(limits=1):
+        for i, s in enumerate(seeds):
+            X, k, np_seed, pm, ofs = draw_cluster_case(s)
+            with contextlib.redirect_stdout(io.StringIO()):
+                np.random.seed(np_seed)
+                if pm is None:
+                    labels, sizes = mods["pccs"].cluster_data(X.copy(), k)
+                else:
+                    labels, sizes = mods["xoe"].cluster_data(X.copy(), n_cluster=k, save_dir=None,
+                                                             args=argparse.Namespace(pm=pm, obs_feat_size=ofs))
+            row = dict(n=X.shape[0], d=X.shape[1], k=k, np_seed=np_seed, xoe=int(pm is not None), x_crc=crc(X, np.float32),
+                       labels_crc=crc(labels, np.int32), sizes_crc=crc(sizes, np.int64))
+            for key, v in row.items():
+                rec.setdefault(key, []).append(v)
+            if i % 10 == 0:
+                print(i, X.shape, k, pm, flush=True)
+    p = os.path.join(HERE, "g34_cluster_data_sweep.npz")
+    np.savez_compressed(p, seeds=np.asarray(seeds, dtype=np.int64), **{key: np.asarray(v, dtype=np.int64) for key, v in rec.items()})
+    print("wrote", p, os.path.getsize(p), "bytes")
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "cluster":
+        return main_cluster(int(sys.argv[1]), int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "metrics":
         return main_metrics(int(sys.argv[1]), int(sys.argv[2]))
     import torch

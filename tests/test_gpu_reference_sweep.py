@@ -17,7 +17,7 @@ import torch
 from conftest import GOLDEN, load_golden
 
 sys.path.insert(0, GOLDEN)
-from gen_reference_sweep import crc, digests, draw_metrics_case, draw_scene_case  # noqa: E402  (case generators and digests only)
+from gen_reference_sweep import crc, digests, draw_cluster_case, draw_metrics_case, draw_scene_case  # noqa: E402  (case generators and digests only)
 
 pytestmark = pytest.mark.gpu
 
@@ -68,3 +68,26 @@ def test_random_candidate_sets_against_the_reference_metrics(gpu_device):
             assert np.allclose(min_ade.cpu().numpy(), g[f"mode{mode}_mins"][lo:hi, 0], rtol=1e-5, atol=0), info
             assert np.allclose(min_fde.cpu().numpy(), g[f"mode{mode}_mins"][lo:hi, 1], rtol=1e-5, atol=0), info
             assert np.allclose([mean_ade, mean_fde], g[f"mode{mode}_val"][i], rtol=1e-5, atol=0), info
+
+
+def test_cluster_data_dropin_bit_equal_to_the_reference_on_one_thread(gpu_device, monkeypatch):
+    """Fixture G34: the reference's own ``np.random.seed(s); cluster_data(X, K)`` (PCCSNet/utils/utility.py:108-133)
+    and the XOE copy with ``args.pm`` under ``threadpool_limits(1)``, 80 seeded random cases, 20 restarts each.  The
+    drop-ins of the same names, with ``pccs_accel.clustering.SUMS = "sklearn_1t"``, return the reference's labels and
+    size array bit for bit (G15 holds the six reference-sized runs; G8 one XOE case in the default mode)."""
+    import argparse
+    import contextlib
+    import io
+    from pccs_accel import clustering
+    monkeypatch.setattr(clustering, "SUMS", "sklearn_1t")
+    g = load_golden("g34_cluster_data_sweep")
+    bad = []
+    for i, s in enumerate(g["seeds"]):
+        X, k, np_seed, pm, ofs = draw_cluster_case(int(s))
+        assert crc(X, np.float32) == int(g["x_crc"][i]) and int(g["xoe"][i]) == int(pm is not None), i
+        np.random.seed(np_seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            labels, sizes = clustering.cluster_data(X.copy(), k, args=None if pm is None else argparse.Namespace(pm=pm, obs_feat_size=ofs))
+        if crc(labels, np.int32) != int(g["labels_crc"][i]) or crc(sizes, np.int64) != int(g["sizes_crc"][i]):
+            bad.append((i, int(s), X.shape, k, pm))
+    assert not bad, f"{len(bad)} of {len(g['seeds'])} cluster_data runs differ from the reference's: {bad[:10]}"
