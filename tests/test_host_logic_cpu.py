@@ -88,6 +88,17 @@ def test_kmeans_fit_rejects_bad_input_before_any_launch():
         kmeans_fit(np.zeros((10, 4), np.float32), 2)      # not a tensor
 
 
+def test_call_site_summation_mode_is_checked_before_any_launch(monkeypatch):
+    """pccs_accel.clustering.SUMS (the mode of the reference-named call sites) takes 'f64' or 'sklearn_1t' only."""
+    from pccs_accel import clustering
+    assert clustering.SUMS in ("f64", "sklearn_1t")
+    monkeypatch.setattr(clustering, "SUMS", "float32")
+    with pytest.raises(ValueError, match="SUMS"):
+        clustering.k_means_cluster(np.zeros((8, 4), dtype=np.float32), 2)
+    with pytest.raises(ValueError, match="SUMS"):
+        clustering.cluster_data(np.zeros((8, 4), dtype=np.float32), 2)
+
+
 def test_modules_mirror_reference_names():
     import pccs_accel.utils.metrics as M
     import pccs_accel.utils.utility as U
