@@ -5,6 +5,7 @@ Run ONLY in the build container (imports PCCSNet/utils/data_process.py from /roo
     python tests/golden/gen_reference_sweep.py [count] [seed]            # G32, 200 cases from seed 32
     python tests/golden/gen_reference_sweep.py [count] [seed] metrics    # G33, 60 cases from seed 33
     python tests/golden/gen_reference_sweep.py [count] [seed] cluster    # G34, 80 cases from seed 34
+    python tests/golden/gen_reference_sweep.py [count] [seed] glue       # G35, 40 cases from seed 35
 
 Every case draws 1-4 scenes of 1-120 pedestrians (datagen.make_scene_trajectories, every other time jittered into
 positions with full mantissas), an observation length, a radius, a cluster count and random cluster labels, runs the
@@ -21,6 +22,12 @@ per agent the chosen candidate and its (ADE, FDE), and the means the loop report
 other case, the XOE copy with ``args.pm`` / ``args.obs_feat_size`` (MomentaryPrediction/PCCSNet_XOE/utils/utility.py),
 both imported and run under ``threadpool_limits(1)`` (20 restarts, deterministic on one thread) on seeded random
 encodings: digests of the labels and of the size array.
+
+``glue`` (fixture G35): the reference's imported ``get_modality`` (utility.py:98-105: torch.mean per cluster) on random
+encodings and labels, and its imported ``transform_trajectory`` (data_process.py:111-122) on random 4-D and 3-D
+displacements with full mantissas followed by gen_prediction's rotate-back with the same torch calls per agent
+(train_steps.py:253-255): the modalities and decoded trajectories as float32 arrays, the prefix sums as digests
+(sequential float32 adds: bit-exact).
 """
 import argparse
 import contextlib
@@ -184,7 +191,65 @@ def main_cluster(count, seed0):
     print("wrote", p, os.path.getsize(p), "bytes")
 
 
+def draw_glue_case(seed):
+    """(X [n, d], labels int32 [n] with every cluster populated, K, disp [m, k, t, 2], rot [m, 2, 2], last_obs [m, 2])."""
+    rs = np.random.RandomState(seed)
+    n, d, kk = int(rs.randint(50, 4000)), int(rs.choice([96, 64, 128, 48, 20, 7])), int(rs.randint(1, 40))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, kk // 2), 1500, 700)
+    X = X * np.float32(rs.uniform(0.3, 3.0)) + (rs.standard_normal(X.shape) * 1e-3).astype(np.float32)
+    labels = rs.randint(0, kk, size=n).astype(np.int32)
+    labels[rs.choice(n, size=kk, replace=False)] = np.arange(kk, dtype=np.int32)
+    m, k, t = int(rs.randint(1, 9)), int(rs.randint(1, 21)), int(rs.choice([12, 8, 5, 1]))
+    disp = datagen.make_displacements(int(rs.randint(1 << 30)), m, k, t)
+    disp = disp * np.float32(rs.uniform(0.3, 3.0)) + (rs.standard_normal(disp.shape) * 1e-3).astype(np.float32)
+    theta = rs.uniform(-np.pi, np.pi, size=m)
+    rot = np.stack([np.stack([np.cos(theta), -np.sin(theta)], -1), np.stack([np.sin(theta), np.cos(theta)], -1)], 1)
+    last_obs = (rs.standard_normal((m, 2)) * 5.0).astype(np.float32)
+    f32 = lambda a: np.ascontiguousarray(a.astype(np.float32))  # noqa: E731
+    return f32(X), labels, kk, f32(disp), f32(rot), last_obs
+
+
+def main_glue(count, seed0):
+    import torch
+    mods = {}
+    for name in ("utils.utility", "utils.data_process"):
+        for m in [m for m in sys.modules if m == "utils" or m.startswith("utils.")]:
+            del sys.modules[m]
+        sys.path.insert(0, os.path.join(REF, "PCCSNet"))
+        try:
+            mods[name] = importlib.import_module(name)
+        finally:
+            sys.path.remove(os.path.join(REF, "PCCSNet"))
+    utility, dp = mods["utils.utility"], mods["utils.data_process"]
+    seeds = [int(s) for s in np.random.RandomState(seed0).randint(1 << 30, size=count)]
+    out = dict(seeds=np.asarray(seeds, dtype=np.int64))
+    meta = {key: [] for key in ("x_crc", "cum4_crc", "cum3_crc")}
+    for i, s in enumerate(seeds):
+        X, labels, kk, disp, rot, last_obs = draw_glue_case(s)
+        out[f"mod{i}"] = utility.get_modality(torch.from_numpy(X), labels, kk).numpy()
+        cum4 = dp.transform_trajectory(torch.from_numpy(disp.copy())).numpy()
+        cum3 = dp.transform_trajectory(torch.from_numpy(disp[:, 0].copy())).numpy()
+        m, k = disp.shape[:2]
+        full = []
+        for a in range(m):  # train_steps.py:251-255 with batch size 1
+            net_output = dp.transform_trajectory(torch.from_numpy(disp[a].copy()))
+            mat = torch.from_numpy(rot[a:a + 1])
+            output = torch.bmm(mat.repeat(k, 1, 1), net_output.transpose(1, 2)).transpose(1, 2)
+            output += torch.from_numpy(last_obs[a:a + 1]).unsqueeze(0)
+            full.append(output.numpy())
+        out[f"dec{i}"] = np.stack(full)
+        meta["x_crc"].append(crc(X, np.float32) ^ crc(disp, np.float32) ^ crc(rot, np.float32) ^ crc(labels, np.int32))
+        meta["cum4_crc"].append(crc(cum4, np.float32))
+        meta["cum3_crc"].append(crc(cum3, np.float32))
+    out.update({key: np.asarray(v, dtype=np.int64) for key, v in meta.items()})
+    p = os.path.join(HERE, "g35_glue_sweep.npz")
+    np.savez_compressed(p, **out)
+    print("wrote", p, os.path.getsize(p), "bytes")
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "glue":
+        return main_glue(int(sys.argv[1]), int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "cluster":
         return main_cluster(int(sys.argv[1]), int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "metrics":

@@ -5,6 +5,7 @@ k-means arithmetic, PCCSNet/utils/utility.py:121):
 
     python tests/golden/gen_sklearn_sweep.py [count] [seed]            # G30, 240 cases from seed 30
     python tests/golden/gen_sklearn_sweep.py [count] [seed] init       # G31, 160 cases from seed 31
+    python tests/golden/gen_sklearn_sweep.py 0 0 singleton             # G36, one constructed case
 
 For every case it draws (n, d, K, n_init, random_state) and the points (datagen's integer mixture, every other time
 scaled and jittered into floats with full mantissas), runs ``KMeans(K, n_init=n_init, random_state=s).fit(X)`` under
@@ -17,6 +18,13 @@ moved out of reach, so that its cluster starts empty and sklearn relocates it to
 (_k_means_common.pyx:165-200; ONE empty cluster at a time: with more, np.argpartition leaves their order to the
 CPU's SIMD selection kernel) -- over points a third of which may be exact duplicates of other rows (equal distances
 in the E-step: the lowest label wins, _k_means_lloyd.pyx:197-199).
+
+``singleton`` (fixture G36): a relocation that takes a cluster's ONLY member.  Cluster 1 starts empty, the farthest
+point is the single member of cluster 0, so cluster 0 is left without weight and ``_average_centers``
+(_k_means_common.pyx:280-296, in place in index order) gives it the row of the heaviest cluster as it stands -- the
+heaviest is cluster 2, not yet averaged when j = 0 is served: its raw sum.  ``KMeans(3, init=C0, n_init=1,
+max_iter=it)`` for it = 1, 2, 3 on one thread; inputs and results stored whole (51 x 4).  The mirrored case (the
+heaviest cluster first) is stored beside it.
 """
 import os
 import sys
@@ -92,7 +100,42 @@ def main_init(count, seed0):
     print("wrote", p, os.path.getsize(p), "bytes")
 
 
+def singleton_case(mirrored):
+    rs = np.random.RandomState(36)
+    others = (np.array([5.0, 5.0, 5.0, 5.0]) + rs.randint(-300, 301, size=(50, 4)) / 1024.0).astype(np.float32)
+    lone = np.array([[-5.0, 0.0, 0.0, 0.0]], dtype=np.float32)
+    X = np.ascontiguousarray(np.concatenate([lone, others]))
+    C0 = np.array([[-8.0, 0.0, 0.0, 0.0], [100.0, 100.0, 100.0, 100.0], [5.0, 5.0, 5.0, 5.0]], dtype=np.float32)
+    if mirrored:  # the heaviest cluster gets index 0, the lone point's cluster index 2
+        C0 = np.ascontiguousarray(C0[::-1])
+    return X, C0
+
+
+def main_singleton():
+    import warnings
+    from sklearn.cluster import KMeans
+    from threadpoolctl import threadpool_limits
+    out = {}
+    with threadpool_limits(limits=1), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, mirrored in (("a", False), ("b", True)):
+            X, C0 = singleton_case(mirrored)
+            out[f"{tag}_X"], out[f"{tag}_C0"] = X, C0
+            for it in (1, 2, 3):
+                km = KMeans(n_clusters=3, init=C0.copy(), n_init=1, max_iter=it).fit(X)
+                out[f"{tag}_centers{it}"] = km.cluster_centers_.astype(np.float32)
+                out[f"{tag}_labels{it}"] = km.labels_.astype(np.int32)
+                out[f"{tag}_n_iter{it}"] = km.n_iter_
+                out[f"{tag}_inertia{it}"] = np.float64(km.inertia_)
+            print(tag, "after one iteration:", out[f"{tag}_centers1"].tolist(), out[f"{tag}_labels1"][:4])
+    p = os.path.join(HERE, "g36_relocation_takes_only_member.npz")
+    np.savez_compressed(p, **out)
+    print("wrote", p, os.path.getsize(p), "bytes")
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "singleton":
+        return main_singleton()
     if len(sys.argv) > 3 and sys.argv[3] == "init":
         return main_init(int(sys.argv[1]), int(sys.argv[2]))
     import sklearn

@@ -17,7 +17,7 @@ import torch
 from conftest import GOLDEN, load_golden
 
 sys.path.insert(0, GOLDEN)
-from gen_reference_sweep import crc, digests, draw_cluster_case, draw_metrics_case, draw_scene_case  # noqa: E402  (case generators and digests only)
+from gen_reference_sweep import crc, digests, draw_cluster_case, draw_glue_case, draw_metrics_case, draw_scene_case  # noqa: E402  (case generators and digests only)
 
 pytestmark = pytest.mark.gpu
 
@@ -91,3 +91,28 @@ def test_cluster_data_dropin_bit_equal_to_the_reference_on_one_thread(gpu_device
         if crc(labels, np.int32) != int(g["labels_crc"][i]) or crc(sizes, np.int64) != int(g["sizes_crc"][i]):
             bad.append((i, int(s), X.shape, k, pm))
     assert not bad, f"{len(bad)} of {len(g['seeds'])} cluster_data runs differ from the reference's: {bad[:10]}"
+
+
+def test_modalities_and_decode_against_the_reference_functions(gpu_device):
+    """Fixture G35: the reference's imported ``get_modality`` (utility.py:98-105) and ``transform_trajectory``
+    (data_process.py:111-122) + gen_prediction's rotate-back (train_steps.py:253-255) on 40 seeded random cases with
+    full-mantissa values.  The drop-ins: modalities to 1e-5 (double sums rounded once against torch's float32 mean;
+    atol 2e-6 for the entries that cancel to ~0), the prefix sums bit for bit (4-D and 3-D, in place), the decoded
+    trajectories to 1e-5."""
+    from pccs_accel import kernels as K
+    from pccs_accel.utils.data_process import transform_trajectory
+    from pccs_accel.utils.utility import get_modality
+    g = load_golden("g35_glue_sweep")
+    for i, s in enumerate(g["seeds"]):
+        X, labels, kk, disp, rot, last_obs = draw_glue_case(int(s))
+        assert crc(X, np.float32) ^ crc(disp, np.float32) ^ crc(rot, np.float32) ^ crc(labels, np.int32) == int(g["x_crc"][i]), i
+        mod = get_modality(torch.from_numpy(X), labels, kk)            # CPU tensor in, as at train_steps.py:356
+        assert mod.dtype == torch.float32 and not mod.is_cuda
+        assert np.allclose(mod.numpy(), g[f"mod{i}"], rtol=1e-5, atol=2e-6), (i, X.shape, kk)
+        d4 = torch.from_numpy(disp.copy()).to(gpu_device)
+        assert transform_trajectory(d4) is d4 and crc(d4.cpu().numpy(), np.float32) == int(g["cum4_crc"][i]), (i, disp.shape)
+        d3 = torch.from_numpy(disp[:, 0].copy()).to(gpu_device)
+        assert crc(transform_trajectory(d3).cpu().numpy(), np.float32) == int(g["cum3_crc"][i]), (i, disp.shape)
+        dec = K.decode_trajectories(torch.from_numpy(disp).to(gpu_device), torch.from_numpy(rot).to(gpu_device),
+                                    torch.from_numpy(last_obs).to(gpu_device))
+        assert np.allclose(dec.cpu().numpy(), g[f"dec{i}"], rtol=1e-5, atol=1e-6), (i, disp.shape)

@@ -62,3 +62,28 @@ def test_random_fits_from_given_centres_bit_equal_to_sklearn_on_one_thread(gpu_d
         if not all(got.values()):
             bad.append((i, int(s), X.shape, k, [name for name, ok in got.items() if not ok]))
     assert not bad, f"{len(bad)} of {len(g['seeds'])} fits differ from sklearn's: {bad[:10]}"
+
+
+@pytest.mark.parametrize("sums", ["sklearn_1t", "f64"])
+def test_relocation_that_takes_a_clusters_only_member(sums, gpu_device):
+    """Fixture G36 (sklearn on one thread, constructed): the relocated far point was the only member of its cluster,
+    which ``_average_centers`` then fills with the heaviest cluster's row as it stands in its in-place loop -- the raw
+    sum if that cluster has the higher index (case a), the averaged centre otherwise (case b).  k_mstep_finish
+    reproduces both (found by the sweep as an oracle infidelity: the product had it right).  1-3 iterations; the
+    one-thread mode bit for bit, the default mode to 1e-5 with identical labels."""
+    import warnings
+    from pccs_accel import clustering
+    g = load_golden("g36_relocation_takes_only_member")
+    for tag in ("a", "b"):
+        X, C0 = g[f"{tag}_X"], g[f"{tag}_C0"]
+        for it in (1, 2, 3):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                fit = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), 3, init=C0, n_init=1, max_iter=it, sums=sums)
+            centers, labels = fit["centers"].cpu().numpy(), fit["labels"].cpu().numpy()
+            assert np.array_equal(labels, g[f"{tag}_labels{it}"]) and fit["n_iter"] == int(g[f"{tag}_n_iter{it}"]), (tag, it)
+            if sums == "sklearn_1t":
+                assert np.array_equal(centers.view(np.uint32), g[f"{tag}_centers{it}"].view(np.uint32)), (tag, it)
+                assert fit["inertia"] == float(g[f"{tag}_inertia{it}"])
+            else:
+                assert np.allclose(centers, g[f"{tag}_centers{it}"], rtol=1e-5, atol=1e-6), (tag, it)
