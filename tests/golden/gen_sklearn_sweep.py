@@ -6,6 +6,7 @@ k-means arithmetic, PCCSNet/utils/utility.py:121):
     python tests/golden/gen_sklearn_sweep.py [count] [seed]            # G30, 240 cases from seed 30
     python tests/golden/gen_sklearn_sweep.py [count] [seed] init       # G31, 160 cases from seed 31
     python tests/golden/gen_sklearn_sweep.py 0 0 singleton             # G36, one constructed case
+    python tests/golden/gen_sklearn_sweep.py [count] [seed] kpp        # G37, 120 cases from seed 37
 
 For every case it draws (n, d, K, n_init, random_state) and the points (datagen's integer mixture, every other time
 scaled and jittered into floats with full mantissas), runs ``KMeans(K, n_init=n_init, random_state=s).fit(X)`` under
@@ -25,6 +26,10 @@ point is the single member of cluster 0, so cluster 0 is left without weight and
 heaviest is cluster 2, not yet averaged when j = 0 is served: its raw sum.  ``KMeans(3, init=C0, n_init=1,
 max_iter=it)`` for it = 1, 2, 3 on one thread; inputs and results stored whole (51 x 4).  The mirrored case (the
 heaviest cluster first) is stored beside it.
+
+``kpp`` (fixture G37): sklearn's public ``kmeans_plusplus(X, K, random_state=s)`` alone (cluster/_kmeans.py:174-272)
+on one thread: K from 1 to 60 and, every fifth case, 410 / 700 / 1100 / 1250 (8 and 9 local trials), feature sizes on
+and off the MFMA path, centred full-mantissa points.  The K chosen row indices, whole.
 """
 import os
 import sys
@@ -133,7 +138,44 @@ def main_singleton():
     print("wrote", p, os.path.getsize(p), "bytes")
 
 
+def draw_kpp_case(seed):
+    """(X centred float32 [n, d], K, random_state) of G37's case ``seed``."""
+    rs = np.random.RandomState(seed)
+    k = int(rs.choice([410, 700, 1100, 1250])) if rs.rand() < 0.2 else int(rs.randint(1, 61))
+    n = int(rs.randint(k + 10, max(k + 11, 6000)))
+    d = int(rs.choice([64, 96, 128, 96, int(rs.randint(1, 41)), 4 * int(rs.randint(1, 60))]))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, 40, 1500, 700)
+    if rs.rand() < 0.5:
+        X = X * np.float32(rs.uniform(0.3, 3.0)) + (rs.standard_normal(X.shape) * 1e-3).astype(np.float32)
+    X = X - X.mean(axis=0)
+    return np.ascontiguousarray(X.astype(np.float32)), k, int(rs.randint(1 << 30))
+
+
+def main_kpp(count, seed0):
+    from sklearn.cluster import kmeans_plusplus
+    from threadpoolctl import threadpool_limits
+    seeds = [int(s) for s in np.random.RandomState(seed0).randint(1 << 30, size=count)]
+    out = dict(seeds=np.asarray(seeds, dtype=np.int64), x_crc=[], k=[])
+    with threadpool_limits(limits=1):
+        for i, s in enumerate(seeds):
+            X, k, state = draw_kpp_case(s)
+            _, idx = kmeans_plusplus(X, k, random_state=state)
+            _, again = kmeans_plusplus(X, k, random_state=state)
+            assert np.array_equal(idx, again)
+            out[f"idx{i}"] = np.asarray(idx, dtype=np.int32)
+            out["x_crc"].append(crc(X, np.float32))
+            out["k"].append(k)
+            if i % 20 == 0:
+                print(i, X.shape, k, flush=True)
+    out["x_crc"], out["k"] = np.asarray(out["x_crc"], dtype=np.int64), np.asarray(out["k"], dtype=np.int64)
+    p = os.path.join(HERE, "g37_kmeanspp_sweep.npz")
+    np.savez_compressed(p, **out)
+    print("wrote", p, os.path.getsize(p), "bytes")
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "kpp":
+        return main_kpp(int(sys.argv[1]), int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "singleton":
         return main_singleton()
     if len(sys.argv) > 3 and sys.argv[3] == "init":

@@ -17,7 +17,7 @@ import torch
 from conftest import GOLDEN, load_golden
 
 sys.path.insert(0, GOLDEN)
-from gen_sklearn_sweep import crc, draw_case, draw_init_case  # noqa: E402  (the case generators only; sklearn is not imported)
+from gen_sklearn_sweep import crc, draw_case, draw_init_case, draw_kpp_case  # noqa: E402  (the case generators only; sklearn is not imported)
 
 pytestmark = pytest.mark.gpu
 
@@ -87,3 +87,22 @@ def test_relocation_that_takes_a_clusters_only_member(sums, gpu_device):
                 assert fit["inertia"] == float(g[f"{tag}_inertia{it}"])
             else:
                 assert np.allclose(centers, g[f"{tag}_centers{it}"], rtol=1e-5, atol=1e-6), (tag, it)
+
+
+def test_random_seedings_equal_sklearns_kmeans_plusplus(gpu_device):
+    """Fixture G37: sklearn's public ``kmeans_plusplus(X, K, random_state=s)`` on one thread, 120 seeded random cases --
+    K 1 ... 60 and 25 cases with K = 410 / 700 / 1100 / 1250 (8 and 9 local trials), feature sizes on and off the MFMA
+    path (down to D = 1), full-mantissa points.  mtp_kmeans_plusplus_f32 with the potentials in the reference stack's
+    float order picks sklearn's K rows, every one of them, in every case."""
+    from pccs_accel import seeding
+    g = load_golden("g37_kmeanspp_sweep")
+    bad = []
+    for i, s in enumerate(g["seeds"]):
+        X, k, state = draw_kpp_case(int(s))
+        assert k == int(g["k"][i]) and crc(X, np.float32) == int(g["x_crc"][i]), f"case {i}: not the generator's points"
+        centers, idx = seeding.kmeans_plusplus(torch.from_numpy(X).to(gpu_device), k, np.random.RandomState(state))
+        got = idx.cpu().numpy()
+        if not np.array_equal(got, g[f"idx{i}"]):
+            bad.append((i, int(s), X.shape, k, int(np.argmax(got != g[f"idx{i}"]))))
+        assert np.array_equal(centers.cpu().numpy(), X[got])
+    assert not bad, f"{len(bad)} of {len(g['seeds'])} seedings differ from sklearn's: {bad[:10]}"
