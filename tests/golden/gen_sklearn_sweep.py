@@ -7,6 +7,7 @@ k-means arithmetic, PCCSNet/utils/utility.py:121):
     python tests/golden/gen_sklearn_sweep.py [count] [seed] init       # G31, 160 cases from seed 31
     python tests/golden/gen_sklearn_sweep.py 0 0 singleton             # G36, one constructed case
     python tests/golden/gen_sklearn_sweep.py [count] [seed] kpp        # G37, 120 cases from seed 37
+    python tests/golden/gen_sklearn_sweep.py [count] [seed] multi      # G38, 120 cases from seed 38
 
 For every case it draws (n, d, K, n_init, random_state) and the points (datagen's integer mixture, every other time
 scaled and jittered into floats with full mantissas), runs ``KMeans(K, n_init=n_init, random_state=s).fit(X)`` under
@@ -30,6 +31,12 @@ heaviest cluster first) is stored beside it.
 ``kpp`` (fixture G37): sklearn's public ``kmeans_plusplus(X, K, random_state=s)`` alone (cluster/_kmeans.py:174-272)
 on one thread: K from 1 to 60 and, every fifth case, 410 / 700 / 1100 / 1250 (8 and 9 local trials), feature sizes on
 and off the MFMA path, centred full-mantissa points.  The K chosen row indices, whole.
+
+``multi`` (fixture G38): G31 with SEVERAL centres out of reach, so that sklearn relocates several empty clusters in one
+iteration.  Which far point goes to which empty cluster is then left to ``np.argpartition``'s SIMD selection kernel
+(unspecified; sklearn's own test accepts either outcome), so the result is stored up to the names of the clusters:
+n_iter, the inertia's bits (a chain over the points: independent of the names), and digests of the labels renamed
+in order of first appearance, of the sorted sizes and of the centres sorted as rows.
 """
 import os
 import sys
@@ -173,7 +180,58 @@ def main_kpp(count, seed0):
     print("wrote", p, os.path.getsize(p), "bytes")
 
 
+def draw_multi_case(seed):
+    """(X, C0) of G38's case ``seed``: 2 ... K-1 initial centres out of reach."""
+    rs = np.random.RandomState(seed)
+    n = int(rs.randint(200, 6000))
+    d = int(rs.choice([64, 96, 128, 96, int(rs.randint(2, 41)), 4 * int(rs.randint(1, 60))]))
+    k = int(min(rs.randint(4, 80), n // 4))
+    X = datagen.make_encodings(int(rs.randint(1 << 30)), n, d, max(1, k // 2), 1500, 700)
+    if rs.rand() < 0.5:
+        X = X * np.float32(rs.uniform(0.3, 3.0)) + (rs.standard_normal(X.shape) * 1e-3).astype(np.float32)
+    X = np.ascontiguousarray(X.astype(np.float32))
+    C0 = X[rs.choice(n, size=k, replace=False)].copy()
+    C0[rs.choice(k, size=int(rs.randint(2, k)), replace=False)] += np.float32(50.0)
+    return X, C0
+
+
+def canonical(labels, centers):
+    """(labels renamed in order of first appearance, sizes sorted, centres sorted as rows): what is left of a result
+    when the names of the clusters do not count."""
+    labels = np.asarray(labels)
+    _, first = np.unique(labels, return_index=True)
+    rename = np.full(int(labels.max()) + 1, -1, dtype=np.int64)
+    rename[labels[np.sort(first)]] = np.arange(len(first))
+    c = np.ascontiguousarray(centers, dtype=np.float32)
+    return rename[labels].astype(np.int32), np.sort(np.bincount(labels)).astype(np.int64), c[np.lexsort(c.T[::-1])]
+
+
+def main_multi(count, seed0):
+    from sklearn.cluster import KMeans
+    from threadpoolctl import threadpool_limits
+    seeds = [int(s) for s in np.random.RandomState(seed0).randint(1 << 30, size=count)]
+    rec = {key: [] for key in ("n", "d", "k", "x_crc", "n_iter", "inertia", "labels_crc", "centers_crc", "sizes_crc")}
+    with threadpool_limits(limits=1):
+        for i, s in enumerate(seeds):
+            X, C0 = draw_multi_case(s)
+            k = C0.shape[0]
+            km = KMeans(n_clusters=k, init=C0.copy(), n_init=1).fit(X)
+            lab, sizes, cen = canonical(km.labels_, km.cluster_centers_)
+            for key, v in (("n", X.shape[0]), ("d", X.shape[1]), ("k", k), ("x_crc", crc(X, np.float32) ^ crc(C0, np.float32)),
+                           ("n_iter", km.n_iter_), ("inertia", np.float64(km.inertia_)), ("labels_crc", crc(lab, np.int32)),
+                           ("centers_crc", crc(cen, np.float32)), ("sizes_crc", crc(sizes, np.int64))):
+                rec[key].append(v)
+            if i % 20 == 0:
+                print(i, X.shape, k, km.n_iter_, flush=True)
+    p = os.path.join(HERE, "g38_sklearn_multi_relocation_sweep.npz")
+    np.savez_compressed(p, seeds=np.asarray(seeds, dtype=np.int64),
+                        **{key: np.asarray(v, dtype=np.float64 if key == "inertia" else np.int64) for key, v in rec.items()})
+    print("wrote", p, os.path.getsize(p), "bytes")
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "multi":
+        return main_multi(int(sys.argv[1]), int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "kpp":
         return main_kpp(int(sys.argv[1]), int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "singleton":

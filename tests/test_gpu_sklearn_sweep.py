@@ -17,7 +17,7 @@ import torch
 from conftest import GOLDEN, load_golden
 
 sys.path.insert(0, GOLDEN)
-from gen_sklearn_sweep import crc, draw_case, draw_init_case, draw_kpp_case  # noqa: E402  (the case generators only; sklearn is not imported)
+from gen_sklearn_sweep import canonical, crc, draw_case, draw_init_case, draw_kpp_case, draw_multi_case  # noqa: E402  (the case generators only; sklearn is not imported)
 
 pytestmark = pytest.mark.gpu
 
@@ -106,3 +106,26 @@ def test_random_seedings_equal_sklearns_kmeans_plusplus(gpu_device):
             bad.append((i, int(s), X.shape, k, int(np.argmax(got != g[f"idx{i}"]))))
         assert np.array_equal(centers.cpu().numpy(), X[got])
     assert not bad, f"{len(bad)} of {len(g['seeds'])} seedings differ from sklearn's: {bad[:10]}"
+
+
+def test_several_relocations_at_once_equal_sklearn_up_to_cluster_names(gpu_device):
+    """Fixture G38: 120 sklearn runs on one thread from given centres with 2 ... K-1 of them out of reach -- several
+    empty clusters relocated in one iteration.  Which far point goes to which empty cluster is np.argpartition's
+    business in sklearn and "descending distance" here (DESIGN.md deviation (iv)), so the names of the relocated
+    clusters may differ; everything else may not: n_iter, the inertia to the last bit, the partition (labels renamed
+    in order of first appearance), the sizes and the centres as a set of rows, bit for bit."""
+    from pccs_accel import clustering
+    g = load_golden("g38_sklearn_multi_relocation_sweep")
+    bad = []
+    for i, s in enumerate(g["seeds"]):
+        X, C0 = draw_multi_case(int(s))
+        k = C0.shape[0]
+        assert crc(X, np.float32) ^ crc(C0, np.float32) == int(g["x_crc"][i]), f"case {i}: not the generator's inputs"
+        fit = clustering.kmeans_fit(torch.from_numpy(X).to(gpu_device), k, init=C0, n_init=1, sums="sklearn_1t")
+        lab, sizes, cen = canonical(fit["labels"].cpu().numpy(), fit["centers"].cpu().numpy())
+        got = dict(n_iter=fit["n_iter"] == int(g["n_iter"][i]), inertia=fit["inertia"] == float(g["inertia"][i]),
+                   partition=crc(lab, np.int32) == int(g["labels_crc"][i]), sizes=crc(sizes, np.int64) == int(g["sizes_crc"][i]),
+                   centers=crc(cen, np.float32) == int(g["centers_crc"][i]))
+        if not all(got.values()):
+            bad.append((i, int(s), X.shape, k, [name for name, ok in got.items() if not ok]))
+    assert not bad, f"{len(bad)} of {len(g['seeds'])} fits differ from sklearn's beyond the names of the clusters: {bad[:10]}"
