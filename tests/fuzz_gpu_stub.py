@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised sweep of the in-library sharded Lloyd loop (mtp_lloyd_sharded_f32) over the stub collectives:
-2-5 ranks as processes on cuda:0 (tests/stub_nccl, see tests/test_gpu_dist_stub.py), random shapes, random
+2-8 ranks as processes on cuda:0 (tests/stub_nccl, see tests/test_gpu_dist_stub.py), random shapes, random
 and ragged row splits (ranks without rows anywhere), unreachable centres (relocation through the all-gathers),
 random check_every, against the one-GPU mtp_lloyd_f32 run of the same case.  Development aid, run on the MI355X box:
 
@@ -171,7 +171,7 @@ def main():
     n_cases = n_checks = n_reloc = n_empty_rank = 0
     fails = []
     while time.time() - t0 < budget:
-        world = int(rs.choice([2, 3, 4, 5]))
+        world = int(rs.choice([2, 3, 4, 5, 8]))
         seeds = [int(s) for s in rs.randint(1 << 30, size=CASES_PER_SPAWN)]
         fd, rdv = tempfile.mkstemp(prefix="mtp_rdv_")
         os.close(fd)
